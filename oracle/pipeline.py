@@ -1,0 +1,77 @@
+"""Oracle try-on pipeline (pure torch, fp32, CPU).  TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+Restates `StableDiffusionXLInpaintPipeline.__call__` (src/tryon_pipeline.py:1254-1894) for the path
+`inference.py:397-414` takes (strength=1.0, 13-channel UNet, CFG on, precomputed prompt embeds), in the reference's
+own execution order (including the 2N-query self-attention and the zeros-cat of the garment features), with every
+random draw supplied by the caller in the order of SURVEY.md A.4 so the run is device-independent.
+
+CLIP encoders (encode_prompt / encode_image) are outside the loop and not restated: the caller passes
+prompt embeddings and the CLIP-H penultimate hidden states `[uncond ; cond]` directly.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def preprocess_image(image):
+    """VaeImageProcessor.preprocess for a [0,1] tensor batch: 2x-1."""
+    return 2.0 * image - 1.0
+
+
+def preprocess_mask(mask):
+    """mask_processor (do_binarize, no normalise): >=0.5 -> 1 (tryon_pipeline.py:419-422)."""
+    return (mask >= 0.5).to(mask.dtype)
+
+
+@torch.no_grad()
+def run(unet, unet_encoder, vae, sched, *, image, mask_image, pose_img, cloth, prompt_embeds, negative_prompt_embeds,
+        pooled_prompt_embeds, negative_pooled_prompt_embeds, text_embeds_cloth, ip_hidden_states, noise,
+        num_inference_steps=30, guidance_scale=2.0, height=None, width=None, return_latents=False, trace=None):
+    """noise: dict(latents[B,4,h,w], masked[B,4,h,w], pose[B,4,h,w], cloth[B,4,h,w], steps[n,B,4,h,w]).
+
+    `trace`: optional dict that receives intermediate tensors for per-stage parity checks.
+    """
+    B = image.shape[0]
+    height = height or image.shape[-2]
+    width = width or image.shape[-1]
+    sf = vae.cfg.scaling_factor
+    timesteps = sched.set_timesteps(num_inference_steps)                                # :1561-1567 (strength 1.0)
+
+    init_image = preprocess_image(image).float()                                        # :1588-1591
+    mask = preprocess_mask(mask_image)                                                  # :1593-1595
+    masked_image = init_image * (mask < 0.5)                                            # :1602
+
+    latents = noise["latents"] * sched.init_noise_sigma                                 # :889-893  (RNG #1)
+    mask_l = F.interpolate(mask, size=(height // 8, width // 8))                        # :939-941 (nearest)
+    mask_l = torch.cat([mask_l] * 2)                                                    # :955
+    masked_lat = sf * vae.encode_sample(masked_image, noise["masked"])                  # :964 -> :911-932 (RNG #2)
+    masked_lat = torch.cat([masked_lat] * 2)                                            # :977-979
+    pose_lat = sf * vae.encode_sample(pose_img, noise["pose"])                          # :1644-1647 (RNG #3)
+    pose_lat = torch.cat([pose_lat] * 2)                                                # :1649-1652
+    cloth_lat = sf * vae.encode_sample(cloth, noise["cloth"])                           # :1654 (RNG #4)
+
+    add_time_ids = torch.tensor([[height, width, 0, 0, height, width]], dtype=prompt_embeds.dtype)  # :1681-1705
+    add_time_ids = add_time_ids.repeat(2 * B, 1)                                        # :1707-1713 (neg == pos here)
+    pe = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)                      # :1710
+    add_text = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0)  # :1711
+    image_embeds = unet.encoder_hid_proj(ip_hidden_states)                              # :1726
+    added = {"text_embeds": add_text, "time_ids": add_time_ids, "image_embeds": image_embeds}
+    if trace is not None:
+        trace.update(masked_lat=masked_lat, pose_lat=pose_lat, cloth_lat=cloth_lat, image_embeds=image_embeds,
+                     mask_l=mask_l, latents0=latents.clone(), step_latents=[], step_eps=[])
+
+    for i, t in enumerate(timesteps):                                                   # :1765
+        lmi = torch.cat([latents] * 2)                                                  # :1769 (scale_model_input = id)
+        lmi = torch.cat([lmi, mask_l, masked_lat, pose_lat], dim=1)                     # :1777
+        _, feats = unet_encoder(cloth_lat, t, text_embeds_cloth)                        # :1787
+        feats = [torch.cat([torch.zeros_like(d), d]) for d in feats]                    # :1796
+        eps = unet(lmi, t, pe, added_cond_kwargs=added, garment_features=feats)[0]      # :1799-1808
+        eu, et = eps.chunk(2)                                                           # :1815
+        eps = eu + guidance_scale * (et - eu)                                           # :1816
+        latents = sched.step(eps, t, latents, noise["steps"][i] if noise.get("steps") is not None else None)  # :1823
+        if trace is not None:
+            trace["step_eps"].append(eps.clone())
+            trace["step_latents"].append(latents.clone())
+    if return_latents:
+        return latents
+    img = vae.decode(latents / sf)                                                      # :1876
+    return (img / 2 + 0.5).clamp(0, 1)                                                  # postprocess
