@@ -1,0 +1,262 @@
+// attention.hip -- flash attention for head_dim 64 on MFMA 32x32x16 (see include/idmvton_hip.h, idmvton_attn_fwd).
+//
+// Swapped formulation: S^T = K.Q^T and O^T = V^T.P^T, so every lane owns ONE query row (q = lane&31; the two half-waves
+// hold different keys of that row).  Row max / row sum / the O rescale are then lane-local (one cross-half exchange per
+// tile for the max), and P goes from the S^T accumulator straight into the PV MFMA "B" operand with no shuffle: the
+// key <-> k-slot assignment of the PV contraction is chosen to be exactly the one the QK^T accumulator already has
+// (slot jj of half-wave u  <->  key 16*step + (jj&3) + 8*(jj>>2) + 4u), and the V^T fragment reads use the same map.
+// V arrives already transposed ([channel][key], written by the projection GEMM's vt epilogue), so K tiles ([key][64 d])
+// and V^T tiles ([64 d][key]) are both 64 rows x 128 B and share one LDS-DMA loader and one XOR swizzle
+// (row r, 16-byte chunk c stored at r*128 + ((c ^ ((r>>1)&7))<<4); swizzle applied on the DMA source address).
+// Key segments: SELF mode walks up to two segments under one softmax (own tokens, garment tokens); a segment that is
+// absent for this batch element (CFG-unconditional half: all-zero garment features) contributes nk keys with logit 0 and
+// value 0 in closed form (m0 = 0, l0 = nk).  CROSS mode keeps the two segments as separate softmaxes and sums the outputs.
+// Pipeline: 2 LDS buffers (16 KiB each), one barrier per 64-key tile: wait(t) -> barrier -> DMA(t+1) -> MFMA/softmax(t).
+#include "common.cuh"
+
+struct AttnParams {
+    int B, heads, Nq;
+    const void* q; int ldq;
+    void* out; int ldo;
+    int nseg;
+    const void* k[2]; int ldk[2]; uint32_t kbytes[2];
+    const void* vt[2]; int ldvt[2]; uint32_t vtbytes[2];
+    int nk[2]; int krows[2]; int seg_b0[2];
+    float ip_scale;
+    int nqb;
+};
+
+#define NEG_BIG (-1.0e30f)
+
+template <typename T, int MODE, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
+    typedef typename VT<T>::v8 v8;
+    typedef typename VT<T>::v4 v4;
+    constexpr int QB = 32 * NWAVES;
+    constexpr int IPW = 16 / NWAVES;                    // DMA instructions per wave per KV tile (8 K + 8 V^T in total)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];   // [buf][K 8 KiB | V^T 8 KiB]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
+    const int u = lane >> 5, l31 = lane & 31;
+
+    const int wg = xcd_remap(blockIdx.x, p.nqb * p.heads * p.B);
+    const int bh = wg / p.nqb, qb = wg - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    // ---- Q fragments (MFMA B operand): column q = l31, k = d in [16s + 8u, +8) ----
+    const int q_row = qb * QB + wave * 32 + l31;
+    const int q_ld = q_row < p.Nq ? q_row : p.Nq - 1;
+    const T* qp = (const T*)p.q + ((size_t)b * p.Nq + q_ld) * p.ldq + h * 64 + 8 * u;
+    v8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(qp + 16 * s);
+
+    // ---- which segments exist for this batch element (block-uniform) ----
+    const bool pres0 = p.nseg > 0 && b >= p.seg_b0[0];
+    const bool pres1 = p.nseg > 1 && b >= p.seg_b0[1];
+    const int nt0 = pres0 ? (p.nk[0] + 63) >> 6 : 0;
+    const int nt1 = pres1 ? (p.nk[1] + 63) >> 6 : 0;
+    const int nt = nt0 + nt1;
+
+    // ---- loader ----
+    const int lrow = lane >> 3, lslot = lane & 7;
+    auto issue = [&](int t, int buf) {
+        const int sg = t < nt0 ? 0 : 1;
+        const int kt = sg ? t - nt0 : t;
+        const int nk = p.nk[sg];
+        const int bsg = b - p.seg_b0[sg];
+        char* dst = smem + buf * 16384 + wave * (IPW * 1024);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int j = wave * IPW + i;               // wave-uniform: 0..7 -> K rows, 8..15 -> V^T rows
+            const int R = (j & 7) * 8 + lrow;
+            const int c = lslot ^ ((R >> 1) & 7);
+            if (j < 8) {
+                const int key = kt * 64 + R;
+                const uint32_t off = (uint32_t)((((size_t)bsg * p.krows[sg] + key) * p.ldk[sg] + h * 64 + c * 8) * 2);
+                dma16(make_rsrc(p.k[sg], p.kbytes[sg]), dst + i * 1024, key < nk ? off : OOB_SENTINEL);
+            } else {
+                const int key0 = kt * 64 + c * 8;
+                const uint32_t off = (uint32_t)((((size_t)bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + key0) * 2);
+                dma16(make_rsrc(p.vt[sg], p.vtbytes[sg]), dst + i * 1024, key0 < nk ? off : OOB_SENTINEL);
+            }
+        }
+    };
+
+    // ---- fragment addresses ----
+    // K (A operand of S^T): row = key kb*32 + l31, chunk 2s + u
+    int k_addr[2], k_swz[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; k_addr[kb] = r * 128; k_swz[kb] = (r >> 1) & 7; }
+    // V^T (A operand of O^T): row = d db*32 + l31; for PV step ks: chunks 2ks and 2ks+1, byte u*8 inside each
+    int v_addr[2], v_swz[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { const int r = db * 32 + l31; v_addr[db] = 8192 + r * 128 + u * 8; v_swz[db] = (r >> 1) & 7; }
+
+    const float cs = 0.125f * 1.44269504088896341f;      // softmax scale (d^-0.5) folded with log2(e)
+    f32x16 oacc[2], ofin[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[db][r] = 0.f; ofin[db][r] = 0.f; }
+    float m_run = NEG_BIG, l_run = 0.f;
+    if (MODE == IDMVTON_ATTN_SELF) {
+        // closed form for absent (all-zero) segments: nk keys with logit 0, value 0
+        int nz = 0;
+        if (p.nseg > 0 && !pres0) nz += p.nk[0];
+        if (p.nseg > 1 && !pres1) nz += p.nk[1];
+        if (nz > 0) { m_run = 0.f; l_run = u == 0 ? (float)nz : 0.f; }
+    }
+
+    if (nt > 0) issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const char* buf = smem + (t & 1) * 16384;
+        const int sg = t < nt0 ? 0 : 1;
+        const int kt = sg ? t - nt0 : t;
+        const int valid = p.nk[sg] - kt * 64;            // keys of this tile that exist (>= 64: all)
+
+        // ---- S^T = K . Q^T ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v8 kf = *(const v8*)(buf + k_addr[kb] + (((2 * s + u) ^ k_swz[kb]) << 4));
+                sacc[kb] = VT<T>::mfma(kf, qf[s], sacc[kb]);
+            }
+        }
+        // ---- online softmax (this lane: one q row, 32 of the tile's 64 keys) ----
+        if (valid < 64) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * u;
+                    if (key >= valid) sacc[kb][r] = NEG_BIG;
+                }
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx * cs);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        v8 pf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], cs, -m_new));
+                psum += pv;
+                pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const v4 lo = *(const v4*)(buf + v_addr[db] + (((2 * ks) ^ v_swz[db]) << 4));
+                const v4 hi = *(const v4*)(buf + v_addr[db] + (((2 * ks + 1) ^ v_swz[db]) << 4));
+                v8 vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                oacc[db] = VT<T>::mfma(vf, pf[ks], oacc[db]);
+            }
+        if (MODE == IDMVTON_ATTN_CROSS) {
+            if (t == nt0 - 1) {                          // end of the text group: finalise it and restart the softmax
+                const float lt = l_run + __shfl_xor(l_run, 32);
+                const float inv = 1.0f / lt;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ofin[db][r] = oacc[db][r] * inv; oacc[db][r] = 0.f; }
+                m_run = NEG_BIG; l_run = 0.f;
+            }
+        }
+    }
+
+    // ---- finalise and store: lane holds O[q][h*64 + db*32 + 8g + 4u + j] ----
+    const float lt = l_run + __shfl_xor(l_run, 32);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    const float sc = MODE == IDMVTON_ATTN_CROSS ? p.ip_scale * inv : inv;
+    if (q_row < p.Nq) {
+        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 4 * u;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (T)(ofin[db][4 * g + j] + oacc[db][4 * g + j] * sc);
+                *(v4*)(op + db * 32 + 8 * g) = o;
+            }
+    }
+}
+
+template <typename T, int MODE>
+static int launch_attn(AttnParams& p, hipStream_t st) {
+    // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
+    const long rows = (long)p.B * p.heads * p.Nq;
+    int nw = 4;
+    if (rows / 128 < 512) nw = 2;
+    if (rows / 128 >= 2048) nw = 8;
+    const int qbs = 32 * nw;
+    p.nqb = (p.Nq + qbs - 1) / qbs;
+    const dim3 grid(p.nqb * p.heads * p.B), block(nw * 64);
+    if (nw == 2) hipLaunchKernelGGL((attn_kernel<T, MODE, 2>), grid, block, 0, st, p);
+    else if (nw == 4) hipLaunchKernelGGL((attn_kernel<T, MODE, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_kernel<T, MODE, 8>), grid, block, 0, st, p);
+    CHECK_LAUNCH("attn_fwd");
+    return IDMVTON_OK;
+}
+
+extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
+    CHECK_ARG(a != nullptr, IDMVTON_E_ARG, "attn_fwd: null args");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "attn_fwd: dtype %d", a->dtype);
+    CHECK_ARG(a->mode == IDMVTON_ATTN_SELF || a->mode == IDMVTON_ATTN_CROSS, IDMVTON_E_ARG, "attn_fwd: mode %d", a->mode);
+    CHECK_ARG(a->B > 0 && a->heads > 0 && a->Nq > 0, IDMVTON_E_SHAPE, "attn_fwd: B=%d heads=%d Nq=%d", a->B, a->heads, a->Nq);
+    CHECK_ARG(a->nseg >= 1 && a->nseg <= 2, IDMVTON_E_SHAPE, "attn_fwd: nseg=%d", a->nseg);
+    if (a->mode == IDMVTON_ATTN_CROSS) CHECK_ARG(a->nseg == 2 && a->seg_b0[0] == 0 && a->seg_b0[1] == 0, IDMVTON_E_ARG,
+                                                 "attn_fwd: CROSS needs two segments present for every batch");
+    CHECK_ARG(a->q && a->out && a->ldq % 8 == 0 && a->ldo % 4 == 0 && ((uintptr_t)a->q & 15) == 0 && ((uintptr_t)a->out & 7) == 0,
+              IDMVTON_E_ALIGN, "attn_fwd: q/out alignment (ldq=%d ldo=%d)", a->ldq, a->ldo);
+    CHECK_ARG(a->ldq >= a->heads * 64 && a->ldo >= a->heads * 64, IDMVTON_E_SHAPE, "attn_fwd: ldq/ldo < heads*64");
+    AttnParams p;
+    p.B = a->B; p.heads = a->heads; p.Nq = a->Nq; p.q = a->q; p.ldq = a->ldq; p.out = a->out; p.ldo = a->ldo;
+    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0;
+    for (int s = 0; s < 2; ++s) {
+        const int ss = s < a->nseg ? s : 0;
+        CHECK_ARG(a->k[ss] && a->vt[ss] && a->nk[ss] > 0 && a->seg_b0[ss] >= 0 && a->seg_b0[ss] <= a->B,
+                  IDMVTON_E_SHAPE, "attn_fwd: seg %d nk=%d b0=%d", ss, a->nk[ss], a->seg_b0[ss]);
+        const int krows = a->k_rows[ss] > 0 ? a->k_rows[ss] : a->nk[ss];
+        CHECK_ARG(krows >= a->nk[ss], IDMVTON_E_SHAPE, "attn_fwd: seg %d k_rows=%d < nk", ss, krows);
+        CHECK_ARG(a->ldk[ss] % 8 == 0 && a->ldvt[ss] % 8 == 0 && a->ldvt[ss] >= ((a->nk[ss] + 7) & ~7) && a->ldk[ss] >= a->heads * 64 &&
+                  ((uintptr_t)a->k[ss] & 15) == 0 && ((uintptr_t)a->vt[ss] & 15) == 0, IDMVTON_E_ALIGN,
+                  "attn_fwd: seg %d ldk=%d ldvt=%d", ss, a->ldk[ss], a->ldvt[ss]);
+        const int nb = a->B - a->seg_b0[ss];
+        const uint64_t kb = (uint64_t)nb * krows * a->ldk[ss] * 2, vb = (uint64_t)nb * a->heads * 64 * a->ldvt[ss] * 2;
+        CHECK_ARG(kb < 0x80000000ull && vb < 0x80000000ull, IDMVTON_E_SHAPE, "attn_fwd: seg %d K/V^T >= 2 GiB", ss);
+        p.k[s] = a->k[ss]; p.ldk[s] = a->ldk[ss]; p.kbytes[s] = (uint32_t)kb;
+        p.vt[s] = a->vt[ss]; p.ldvt[s] = a->ldvt[ss]; p.vtbytes[s] = (uint32_t)vb;
+        p.nk[s] = a->nk[ss]; p.krows[s] = krows; p.seg_b0[s] = a->seg_b0[ss];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == IDMVTON_BF16)
+        return a->mode == IDMVTON_ATTN_SELF ? launch_attn<bf16_t, IDMVTON_ATTN_SELF>(p, st) : launch_attn<bf16_t, IDMVTON_ATTN_CROSS>(p, st);
+    return a->mode == IDMVTON_ATTN_SELF ? launch_attn<f16_t, IDMVTON_ATTN_SELF>(p, st) : launch_attn<f16_t, IDMVTON_ATTN_CROSS>(p, st);
+}

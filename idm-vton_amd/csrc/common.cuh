@@ -1,0 +1,71 @@
+// common.cuh -- shared device/host helpers for the gfx950 kernels of libidmvton_hip.so.
+// CDNA4 only: wave = 64 lanes, MFMA 32x32x16 (bf16/f16 in, f32 accumulate), LDS-DMA (buffer_load ... lds).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/idmvton_hip.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// Per-dtype traits: 8-wide / 4-wide vector types and the 32x32x16 MFMA.
+template <typename T> struct VT;
+template <> struct VT<bf16_t> {
+    typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct VT<f16_t> {
+    typedef f16x8 v8; typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// Wave-uniform value the compiler can prove uniform (needed for M0 / SGPR operands).
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// 16-byte LDS-DMA: every lane supplies a byte offset into the buffer `rs`; lane l's 16 bytes land at
+// lds_base + 16*l (lds_base must be wave-uniform).  Out-of-range offsets (>= num_records) read as zero.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, void* lds_base, uint32_t voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_base), 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+#define OOB_SENTINEL 0x80000000u
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): gives each XCD a contiguous range of tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+int idmvton_set_error(int code, const char* fmt, ...);
+#define CHECK_ARG(cond, code, ...) do { if (!(cond)) return idmvton_set_error(code, __VA_ARGS__); } while (0)
+#define CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
+    return idmvton_set_error(IDMVTON_E_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)

@@ -1,0 +1,155 @@
+// elementwise.hip -- small fused HBM/latency-bound ops of the denoising loop body and the pipeline edges, plus the C-ABI
+// error plumbing and the hardware layout probes.  See include/idmvton_hip.h for the reference call sites.
+#include "common.cuh"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+int idmvton_set_error(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+extern "C" const char* idmvton_last_error(void) { return g_err; }
+extern "C" int idmvton_abi_version(void) { return 1; }
+
+// ---- TryonNet input: cat([latents]*2 | mask | masked | pose) -> NHWC[cpad] (tryon_pipeline.py:1769,1777) ----
+template <typename T>
+__global__ void pack_input_kernel(const idmvton_pack_input_args a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (b2, pixel)
+    const int total = 2 * a.B * a.hw;
+    if (idx >= total) return;
+    const int b2 = idx / a.hw, pix = idx - b2 * a.hw;
+    const int b = b2 % a.B;                                     // both CFG halves see the same latents
+    T* o = (T*)a.out + (size_t)idx * a.cpad;
+    const T* cond = (const T*)a.cond + (size_t)idx * 9;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (T)a.latents[((size_t)b * 4 + c) * a.hw + pix];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[4 + c] = cond[c];
+    for (int c = 13; c < a.cpad; ++c) o[c] = (T)0.f;
+}
+extern "C" int idmvton_pack_input(const idmvton_pack_input_args* a, void* stream) {
+    CHECK_ARG(a && a->latents && a->cond && a->out, IDMVTON_E_ARG, "pack_input: null pointer");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "pack_input: dtype %d", a->dtype);
+    CHECK_ARG(a->B > 0 && a->hw > 0 && a->cpad >= 13, IDMVTON_E_SHAPE, "pack_input: B=%d hw=%d cpad=%d", a->B, a->hw, a->cpad);
+    const int total = 2 * a->B * a->hw;
+    const dim3 grid((total + 255) / 256), block(256);
+    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((pack_input_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((pack_input_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    CHECK_LAUNCH("pack_input");
+    return IDMVTON_OK;
+}
+
+// ---- CFG combine + scheduler step (tryon_pipeline.py:1814-1823) ----
+template <typename T>
+__global__ void cfg_step_kernel(const idmvton_cfg_step_args a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (b, pixel)
+    if (idx >= a.B * a.hw) return;
+    const int b = idx / a.hw, pix = idx - b * a.hw;
+    const float c_x = a.coef[0], c_eps = a.coef[1], sigma = a.coef[2], g = a.coef[3];
+    const T* eu = (const T*)a.eps_nhwc + ((size_t)b * a.hw + pix) * a.ldc;
+    const T* ec = (const T*)a.eps_nhwc + ((size_t)(a.B + b) * a.hw + pix) * a.ldc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t o = ((size_t)b * 4 + c) * a.hw + pix;
+        const float u = (float)eu[c], t = (float)ec[c];
+        const float eps = u + g * (t - u);
+        float x = c_x * a.latents[o] + c_eps * eps;
+        if (a.noise) x += sigma * a.noise[o];
+        a.latents[o] = x;
+    }
+}
+extern "C" int idmvton_cfg_step(const idmvton_cfg_step_args* a, void* stream) {
+    CHECK_ARG(a && a->eps_nhwc && a->latents && a->coef, IDMVTON_E_ARG, "cfg_step: null pointer");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "cfg_step: dtype %d", a->dtype);
+    CHECK_ARG(a->B > 0 && a->hw > 0 && a->ldc >= 4, IDMVTON_E_SHAPE, "cfg_step: B=%d hw=%d ldc=%d", a->B, a->hw, a->ldc);
+    const dim3 grid((a->B * a->hw + 255) / 256), block(256);
+    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((cfg_step_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((cfg_step_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    CHECK_LAUNCH("cfg_step");
+    return IDMVTON_OK;
+}
+
+// ---- NCHW fp32 <-> NHWC dtype (channel padded) ----
+template <typename T>
+__global__ void layout_kernel(const idmvton_layout_args a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b, pixel)
+    if (idx >= (size_t)a.B * a.HW) return;
+    const int b = (int)(idx / a.HW), pix = (int)(idx - (size_t)b * a.HW);
+    if (a.to_nhwc) {
+        const float* s = (const float*)a.src;
+        T* d = (T*)a.dst + idx * a.cpad;
+        for (int c = 0; c < a.C; ++c) d[c] = (T)(s[((size_t)b * a.C + c) * a.HW + pix] * a.scale + a.shift);
+        for (int c = a.C; c < a.cpad; ++c) d[c] = (T)0.f;
+    } else {
+        const T* s = (const T*)a.src + idx * a.cpad;
+        float* d = (float*)a.dst;
+        for (int c = 0; c < a.C; ++c) d[((size_t)b * a.C + c) * a.HW + pix] = (float)s[c] * a.scale + a.shift;
+    }
+}
+extern "C" int idmvton_layout(const idmvton_layout_args* a, void* stream) {
+    CHECK_ARG(a && a->src && a->dst, IDMVTON_E_ARG, "layout: null pointer");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "layout: dtype %d", a->dtype);
+    CHECK_ARG(a->B > 0 && a->C > 0 && a->HW > 0 && a->cpad >= a->C, IDMVTON_E_SHAPE, "layout: B=%d C=%d HW=%d cpad=%d", a->B, a->C, a->HW, a->cpad);
+    const size_t total = (size_t)a->B * a->HW;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((layout_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((layout_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    CHECK_LAUNCH("layout");
+    return IDMVTON_OK;
+}
+
+// ---- VAE posterior sample (tryon_pipeline.py:255) ----
+template <typename T>
+__global__ void vae_sample_kernel(const idmvton_vae_sample_args a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.B * a.hw) return;
+    const int b = idx / a.hw, pix = idx - b * a.hw;
+    const T* m = (const T*)a.moments + (size_t)idx * a.ldm;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t o = ((size_t)b * 4 + c) * a.hw + pix;
+        const float mean = (float)m[c];
+        const float lv = fminf(fmaxf((float)m[4 + c], -30.f), 20.f);
+        a.z[o] = (mean + __expf(0.5f * lv) * a.noise[o]) * a.scale;
+    }
+}
+extern "C" int idmvton_vae_sample(const idmvton_vae_sample_args* a, void* stream) {
+    CHECK_ARG(a && a->moments && a->noise && a->z, IDMVTON_E_ARG, "vae_sample: null pointer");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "vae_sample: dtype %d", a->dtype);
+    CHECK_ARG(a->B > 0 && a->hw > 0 && a->ldm >= 8, IDMVTON_E_SHAPE, "vae_sample: B=%d hw=%d ldm=%d", a->B, a->hw, a->ldm);
+    const dim3 grid((a->B * a->hw + 255) / 256), block(256);
+    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((vae_sample_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((vae_sample_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, *a);
+    CHECK_LAUNCH("vae_sample");
+    return IDMVTON_OK;
+}
+
+// ---- hardware layout probes: one wave, one instruction, raw per-lane operands in, raw per-lane results out ----
+// which = 0: mfma_f32_32x32x16_bf16   a,b: [64 lanes][8] bf16 ; c: [64 lanes][16] f32
+// which = 1: mfma_f32_32x32x16_f16
+__global__ void probe_mfma_kernel(int which, const void* a, const void* b, float* c) {
+    const int lane = threadIdx.x;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (which == 0) acc = VT<bf16_t>::mfma(((const bf16x8*)a)[lane], ((const bf16x8*)b)[lane], acc);
+    else acc = VT<f16_t>::mfma(((const f16x8*)a)[lane], ((const f16x8*)b)[lane], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[lane * 16 + r] = acc[r];
+}
+extern "C" int idmvton_probe_mfma(int which, const void* a, const void* b, float* c, void* stream) {
+    CHECK_ARG(a && b && c && (which == 0 || which == 1), IDMVTON_E_ARG, "probe_mfma: bad args");
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, which, a, b, c);
+    CHECK_LAUNCH("probe_mfma");
+    return IDMVTON_OK;
+}
+
+// ---- struct-size self description: lets the host-side binding verify its mirror of include/idmvton_hip.h ----
+extern "C" int idmvton_sizeof(const char* name) {
+#define SZ(n) if (!strcmp(name, #n)) return (int)sizeof(n);
+    SZ(idmvton_seg) SZ(idmvton_gemm_conv_args) SZ(idmvton_attn_args) SZ(idmvton_layernorm_args)
+    SZ(idmvton_groupnorm_args) SZ(idmvton_pack_input_args) SZ(idmvton_cfg_step_args) SZ(idmvton_layout_args)
+    SZ(idmvton_vae_sample_args)
+#undef SZ
+    return -1;
+}

@@ -1,0 +1,202 @@
+// norm.hip -- HBM-bound normalisation kernels: LayerNorm (one wave per token row, row kept in registers, two-pass
+// statistics in fp32, optional second output = GarmentNet feature export) and NHWC GroupNorm(+SiLU) as
+// stats (per-channel fp32 partials -> per-(batch,group) double atomics) + apply (16-byte vector loads/stores, the
+// per-thread channel chunk's scale/shift held in registers).  See include/idmvton_hip.h for the reference call sites.
+#include "common.cuh"
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row; lane l owns 8-element chunks l, l+64, l+128 (C <= 1536).  16-byte loads, fp32 math.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_args a) {
+    typedef typename VT<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int nchunk = a.C >> 3;
+    const T* x = (const T*)a.x + (size_t)row * a.ldx;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const v8 t = *(const v8*)(x + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)a.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+    const T* gamma = (const T*)a.gamma;
+    const T* beta = (const T*)a.beta;
+    T* y = (T*)a.y + (size_t)row * a.ldy;
+    T* y2 = a.y2 ? (T*)a.y2 + (size_t)row * a.ldy2 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const v8 g = *(const v8*)(gamma + c * 8);
+            const v8 bt = *(const v8*)(beta + c * 8);
+            v8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)((v[i][j] - mean) * rstd * (float)g[j] + (float)bt[j]);
+            *(v8*)(y + c * 8) = o;
+            if (y2) *(v8*)(y2 + c * 8) = o;
+        }
+    }
+}
+
+template <typename T>
+static int launch_ln(const idmvton_layernorm_args& a, hipStream_t st) {
+    const dim3 grid((a.rows + 3) / 4), block(256);
+    const int nch = ((a.C >> 3) + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, a);
+    else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, st, a);
+    CHECK_LAUNCH("layernorm");
+    return IDMVTON_OK;
+}
+
+extern "C" int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream) {
+    CHECK_ARG(a != nullptr, IDMVTON_E_ARG, "layernorm: null args");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "layernorm: dtype %d", a->dtype);
+    CHECK_ARG(a->rows > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 1536, IDMVTON_E_SHAPE, "layernorm: rows=%d C=%d (C%%8==0, C<=1536)", a->rows, a->C);
+    CHECK_ARG(a->x && a->y && a->gamma && a->beta, IDMVTON_E_ARG, "layernorm: null pointer");
+    CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && (!a->y2 || a->ldy2 % 8 == 0), IDMVTON_E_ALIGN, "layernorm: ld alignment");
+    CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->y2 | (uintptr_t)a->gamma | (uintptr_t)a->beta) & 15) == 0,
+              IDMVTON_E_ALIGN, "layernorm: pointers must be 16-byte aligned");
+    return a->dtype == IDMVTON_BF16 ? launch_ln<bf16_t>(*a, (hipStream_t)stream) : launch_ln<f16_t>(*a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm (NHWC)
+// Thread -> fixed 8-channel chunk (chunk = tid % (C/8)), striding over pixels.  A chunk may straddle two groups
+// (e.g. C=320: 10 channels per group), so statistics are accumulated per CHANNEL in LDS and folded to groups at the end.
+#define GN_MAXC 2560
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_args a, int pix_per_block) {
+    typedef typename VT<T>::v8 v8;
+    __shared__ float s_sum[GN_MAXC], s_sq[GN_MAXC];
+    const int b = blockIdx.y;
+    const int nchunk = a.C >> 3;
+    for (int c = threadIdx.x; c < a.C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    const int tpp = 256 / nchunk > 0 ? 256 / nchunk : 1;   // pixels processed concurrently per pass
+    const int chunk = threadIdx.x % nchunk, psub = threadIdx.x / nchunk;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, a.HW);
+    // chunks beyond 256 threads (C > 2048): loop over chunk groups
+    for (int cb = chunk; cb < nchunk; cb += 256) {
+        const int c0 = cb * 8;
+        const T* src; int pitch, coff;
+        if (c0 < a.C1) { src = (const T*)a.x; pitch = a.C1; coff = c0; }
+        else { src = (const T*)a.x2; pitch = a.C - a.C1; coff = c0 - a.C1; }
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+        if (psub < tpp) {
+            for (int pix = p0 + psub; pix < p1; pix += tpp) {
+                const v8 t = *(const v8*)(src + ((size_t)b * a.HW + pix) * pitch + coff);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)t[j]; s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&s_sum[c0 + j], s[j]); atomicAdd(&s_sq[c0 + j], q[j]); }
+        }
+    }
+    __syncthreads();
+    const int cpg = a.C / a.groups;
+    for (int g = threadIdx.x; g < a.groups; g += 256) {
+        double ds = 0.0, dq = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { ds += (double)s_sum[c]; dq += (double)s_sq[c]; }
+        atomicAdd(&a.stats[((size_t)b * a.groups + g) * 2 + 0], ds);
+        atomicAdd(&a.stats[((size_t)b * a.groups + g) * 2 + 1], dq);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_args a, int pix_per_block) {
+    typedef typename VT<T>::v8 v8;
+    const int b = blockIdx.y;
+    const int nchunk = a.C >> 3;
+    const int tpp = 256 / nchunk > 0 ? 256 / nchunk : 1;
+    const int chunk = threadIdx.x % nchunk, psub = threadIdx.x / nchunk;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, a.HW);
+    const int cpg = a.C / a.groups;
+    const double cnt = (double)cpg * (double)a.HW;
+    const T* gamma = (const T*)a.gamma;
+    const T* beta = (const T*)a.beta;
+    for (int cb = chunk; cb < nchunk; cb += 256) {
+        const int c0 = cb * 8;
+        const T* src; int pitch, coff;
+        if (c0 < a.C1) { src = (const T*)a.x; pitch = a.C1; coff = c0; }
+        else { src = (const T*)a.x2; pitch = a.C - a.C1; coff = c0 - a.C1; }
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j, g = c / cpg;
+            const double mean = a.stats[((size_t)b * a.groups + g) * 2 + 0] / cnt;
+            double var = a.stats[((size_t)b * a.groups + g) * 2 + 1] / cnt - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            sc[j] = rstd * (float)gamma[c];
+            sh[j] = (float)beta[c] - (float)mean * sc[j];
+        }
+        if (psub < tpp) {
+            T* dst = (T*)a.y;
+            for (int pix = p0 + psub; pix < p1; pix += tpp) {
+                const size_t row = (size_t)b * a.HW + pix;
+                const v8 t = *(const v8*)(src + row * pitch + coff);
+                v8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = (float)t[j] * sc[j] + sh[j];
+                    if (a.silu) f = silu_f(f);
+                    o[j] = (T)f;
+                }
+                *(v8*)(dst + row * a.C + c0) = o;
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_gn(const idmvton_groupnorm_args& a, hipStream_t st) {
+    // ~8 blocks per CU over the whole launch; each block owns a contiguous pixel slab of one batch element.
+    int nblk = (2048 + a.B - 1) / a.B;
+    int ppb = (a.HW + nblk - 1) / nblk;
+    const int nchunk = a.C >> 3;
+    const int tpp = 256 / nchunk > 0 ? 256 / nchunk : 1;
+    if (ppb < tpp * 4) ppb = tpp * 4;
+    nblk = (a.HW + ppb - 1) / ppb;
+    const dim3 grid(nblk, a.B), block(256);
+    hipError_t e = hipMemsetAsync(a.stats, 0, sizeof(double) * 2 * a.B * a.groups, st);
+    if (e != hipSuccess) return idmvton_set_error(IDMVTON_E_LAUNCH, "groupnorm: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((gn_stats_kernel<T>), grid, block, 0, st, a, ppb);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, block, 0, st, a, ppb);
+    CHECK_LAUNCH("groupnorm");
+    return IDMVTON_OK;
+}
+
+extern "C" int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream) {
+    CHECK_ARG(a != nullptr, IDMVTON_E_ARG, "groupnorm: null args");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "groupnorm: dtype %d", a->dtype);
+    CHECK_ARG(a->B > 0 && a->HW > 0 && a->C > 0 && a->groups > 0 && a->C % a->groups == 0 && a->C % 8 == 0 && a->C <= GN_MAXC,
+              IDMVTON_E_SHAPE, "groupnorm: B=%d HW=%d C=%d groups=%d", a->B, a->HW, a->C, a->groups);
+    CHECK_ARG(a->x && a->y && a->gamma && a->beta && a->stats, IDMVTON_E_ARG, "groupnorm: null pointer");
+    CHECK_ARG(a->C1 > 0 && a->C1 <= a->C && a->C1 % 8 == 0 && (a->C1 == a->C || a->x2), IDMVTON_E_SHAPE, "groupnorm: C1=%d", a->C1);
+    CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->x2 | (uintptr_t)a->y) & 15) == 0, IDMVTON_E_ALIGN, "groupnorm: pointer alignment");
+    return a->dtype == IDMVTON_BF16 ? launch_gn<bf16_t>(*a, (hipStream_t)stream) : launch_gn<f16_t>(*a, (hipStream_t)stream);
+}

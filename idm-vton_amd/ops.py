@@ -1,0 +1,198 @@
+"""Thin torch-tensor front end over the C ABI (ffi.py).  Torch is used only for device memory and the current stream.
+
+All activations are NHWC / token-major: a tensor of shape [..., C] with C contiguous.  Every function launches
+asynchronously on `torch.cuda.current_stream()` and returns its output tensor(s).  No function has a CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import ffi
+
+_DT = {torch.float16: ffi.F16, torch.bfloat16: ffi.BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"idm_vton_amd ops take float16/bfloat16 tensors, got {t.dtype}") from None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("idm_vton_amd ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+    return t
+
+
+def _ptr(t):
+    return None if t is None else _dev(t).data_ptr()
+
+
+class SegSpec:
+    """One K-segment of the virtual activation matrix (see include/idmvton_hip.h, idmvton_seg)."""
+    __slots__ = ("t", "coff", "len", "dy", "dx")
+
+    def __init__(self, t, coff, length, dy=0, dx=0):
+        self.t, self.coff, self.len, self.dy, self.dx = t, coff, length, dy, dx
+
+
+def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
+              rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, vt=None, vt_n0=0,
+              vt_tokens=0, tile_hint=0):
+    """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous."""
+    a = ffi.GemmConvArgs()
+    a.dtype = _dt(w)
+    N, Ktot = w.shape
+    a.w, a.N, a.Ktot = _ptr(w), N, Ktot
+    a.nseg = len(segs)
+    for i, s in enumerate(segs):
+        t = _dev(s.t)
+        g = a.seg[i]
+        g.ptr, g.bytes, g.pitch = t.data_ptr(), t.numel() * t.element_size(), t.shape[-1]
+        g.coff, g.len, g.dy, g.dx = s.coff, s.len, s.dy, s.dx
+    Wo = M if Wo is None else Wo
+    Wi = M if Wi is None else Wi
+    a.M, a.Ho, a.Wo, a.Hi, a.Wi, a.stride, a.ups = M, Ho, Wo, Hi, Wi, stride, int(bool(ups))
+    n_out = N // 2 if geglu else (vt_n0 if vt is not None else N)
+    if out is None and n_out > 0:
+        out = torch.empty((M, n_out), dtype=w.dtype, device=w.device)
+    a.out = _ptr(out)
+    a.ldo = (ldo if ldo is not None else (out.stride(-2) if out is not None else 0))
+    a.bias = _ptr(bias)
+    a.rowbias, a.rowbias_ld, a.rows_per_group = _ptr(rowbias), rowbias_ld, rows_per_group
+    a.res = _ptr(res)
+    a.ldr = (ldr if ldr is not None else (res.stride(-2) if res is not None else 0))
+    a.mode = ffi.EPI_GEGLU if geglu else ffi.EPI_NONE
+    a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
+    a.tile_hint = tile_hint
+    ffi.call("idmvton_gemm_conv", a, _stream())
+    return out
+
+
+def linear(x, w, **kw):
+    """x: [M][K] (row stride x.stride(0), K contiguous)."""
+    M, K = x.shape
+    return gemm_conv([SegSpec(x, 0, K)], w, M, **kw)
+
+
+def conv_segs(x, k, pad, coff=0, length=None):
+    """K-segments of a k x k convolution over NHWC tensor x [B][H][W][C] (weights laid out [Cout][ky][kx][C])."""
+    length = x.shape[-1] if length is None else length
+    return [SegSpec(x, coff, length, ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+
+
+def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, Nq=None, ldq=None, ldo=None):
+    """q/out: [B][Nq][>=heads*64] views; segs: list of dict(k=, vt=, nk=, ldk=, ldvt=, k_rows=, b0=)."""
+    a = ffi.AttnArgs()
+    a.dtype, a.mode = _dt(q), mode
+    a.B = q.shape[0] if B is None else B
+    a.Nq = q.shape[1] if Nq is None else Nq
+    a.heads = heads
+    a.q, a.ldq = _ptr(q), (q.stride(-2) if ldq is None else ldq)
+    a.out, a.ldo = _ptr(out), (out.stride(-2) if ldo is None else ldo)
+    a.nseg = len(segs)
+    for i, s in enumerate(segs):
+        a.k[i], a.vt[i] = _ptr(s["k"]), _ptr(s["vt"])
+        a.ldk[i], a.ldvt[i] = s["ldk"], s["ldvt"]
+        a.nk[i], a.k_rows[i], a.seg_b0[i] = s["nk"], s.get("k_rows", 0), s.get("b0", 0)
+    a.ip_scale = ip_scale
+    ffi.call("idmvton_attn_fwd", a, _stream())
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None, out2=None):
+    """x: [rows][C] (row stride x.stride(0))."""
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    a = ffi.LayerNormArgs()
+    a.dtype, a.rows, a.C = _dt(x), rows, Cc
+    a.x, a.ldx = _ptr(x), x.stride(0)
+    a.gamma, a.beta, a.eps = _ptr(gamma), _ptr(beta), eps
+    a.y, a.ldy = _ptr(out), out.stride(0)
+    a.y2, a.ldy2 = _ptr(out2), (out2.stride(0) if out2 is not None else 0)
+    ffi.call("idmvton_layernorm", a, _stream())
+    return out
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu, stats, x2=None, out=None):
+    """x: [B][HW][C1] (+ optional x2 [B][HW][C2], virtually concatenated along C); stats: float64 [B*groups*2]."""
+    B, HW, C1 = x.shape
+    Cc = C1 + (x2.shape[-1] if x2 is not None else 0)
+    if out is None:
+        out = torch.empty((B, HW, Cc), dtype=x.dtype, device=x.device)
+    a = ffi.GroupNormArgs()
+    a.dtype, a.B, a.HW, a.C, a.groups = _dt(x), B, HW, Cc, groups
+    a.x, a.C1, a.x2 = _ptr(x), C1, _ptr(x2)
+    a.gamma, a.beta, a.eps, a.silu = _ptr(gamma), _ptr(beta), eps, int(bool(silu))
+    a.y, a.stats = _ptr(out), _ptr(stats)
+    ffi.call("idmvton_groupnorm", a, _stream())
+    return out
+
+
+def pack_input(latents, cond, out):
+    a = ffi.PackInputArgs()
+    B, hw = latents.shape[0], latents.shape[2] * latents.shape[3] if latents.dim() == 4 else latents.shape[2]
+    a.dtype, a.B, a.hw, a.cpad = _dt(out), B, hw, out.shape[-1]
+    a.latents, a.cond, a.out = _ptr(latents), _ptr(cond), _ptr(out)
+    ffi.call("idmvton_pack_input", a, _stream())
+    return out
+
+
+def cfg_step(eps_nhwc, latents, noise, coef):
+    a = ffi.CfgStepArgs()
+    B = latents.shape[0]
+    hw = latents.numel() // (B * 4)
+    a.dtype, a.B, a.hw, a.ldc = _dt(eps_nhwc), B, hw, eps_nhwc.shape[-1]
+    a.eps_nhwc, a.latents, a.noise, a.coef = _ptr(eps_nhwc), _ptr(latents), _ptr(noise), _ptr(coef)
+    ffi.call("idmvton_cfg_step", a, _stream())
+    return latents
+
+
+def to_nhwc(src_nchw_f32, dtype, cpad=None, scale=1.0, shift=0.0, out=None):
+    B, Cc = src_nchw_f32.shape[:2]
+    HW = src_nchw_f32.numel() // (B * Cc)
+    cpad = Cc if cpad is None else cpad
+    if out is None:
+        out = torch.empty((B, HW, cpad), dtype=dtype, device=src_nchw_f32.device)
+    a = ffi.LayoutArgs()
+    a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = _dt(out), B, Cc, HW, cpad, 1
+    a.src, a.dst, a.scale, a.shift = _ptr(src_nchw_f32), _ptr(out), scale, shift
+    ffi.call("idmvton_layout", a, _stream())
+    return out
+
+
+def to_nchw(src_nhwc, Cc, shape_hw, scale=1.0, shift=0.0, out=None):
+    B, HW, cpad = src_nhwc.shape
+    if out is None:
+        out = torch.empty((B, Cc) + tuple(shape_hw), dtype=torch.float32, device=src_nhwc.device)
+    a = ffi.LayoutArgs()
+    a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = _dt(src_nhwc), B, Cc, HW, cpad, 0
+    a.src, a.dst, a.scale, a.shift = _ptr(src_nhwc), _ptr(out), scale, shift
+    ffi.call("idmvton_layout", a, _stream())
+    return out
+
+
+def vae_sample(moments_nhwc, noise, scale, out=None):
+    B, hw, ldm = moments_nhwc.shape
+    if out is None:
+        out = torch.empty_like(noise)
+    a = ffi.VaeSampleArgs()
+    a.dtype, a.B, a.hw, a.ldm = _dt(moments_nhwc), B, hw, ldm
+    a.moments, a.noise, a.z, a.scale = _ptr(moments_nhwc), _ptr(noise), _ptr(out), scale
+    ffi.call("idmvton_vae_sample", a, _stream())
+    return out
+
+
+def probe_mfma(which, a, b):
+    c = torch.empty((64, 16), dtype=torch.float32, device=a.device)
+    rc = ffi.lib().idmvton_probe_mfma(which, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                      C.c_void_p(c.data_ptr()), C.c_void_p(_stream()))
+    if rc != 0:
+        raise RuntimeError(ffi.lib().idmvton_last_error().decode())
+    return c

@@ -1,0 +1,187 @@
+/* idmvton_hip.h -- C ABI of libidmvton_hip.so (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * The reference (yisol/IDM-VTON) has no FFI of its own: its hot path is Python calling ATen/cuDNN/cuBLAS ops through
+ * diffusers.  Each entry point below therefore cites the reference *call site(s)* whose arithmetic
+ * it replaces.  Conventions (SURVEY.md 8b "C ABI a native replacement must export"):
+ *
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm `tensor.data_ptr()`);
+ *   - `int idmvton_<op>(const idmvton_<op>_args*, void* stream)` returns 0 or a negative IDMVTON_E_* code;
+ *     `idmvton_last_error()` gives a thread-local message; no exceptions, no allocation, no ownership transfer;
+ *   - launches are asynchronous on `stream` (a hipStream_t), no hidden syncs => hipGraph-capturable; stateless.
+ *   - activations are NHWC / token-major ([rows][channels], channels contiguous); "ld*" are in ELEMENTS.
+ */
+#ifndef IDMVTON_HIP_H
+#define IDMVTON_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { IDMVTON_OK = 0, IDMVTON_E_SHAPE = -1, IDMVTON_E_DTYPE = -2, IDMVTON_E_ALIGN = -3, IDMVTON_E_LAUNCH = -4,
+       IDMVTON_E_ARG = -5 };
+enum { IDMVTON_F16 = 0, IDMVTON_BF16 = 1, IDMVTON_F32 = 2 };
+
+const char* idmvton_last_error(void);
+int idmvton_abi_version(void);
+int idmvton_sizeof(const char* struct_name); /* sizeof() of an args struct by name, -1 if unknown (binding self-check) */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_gemm_conv : out[M][N] = epilogue( sum_k X[m][k] * W[n][k] )        (MFMA implicit GEMM, fp32 accumulate)
+ *
+ * Replaces every nn.Linear / nn.Conv2d on the hot path:
+ *   to_q/to_k/to_v/to_out   ip_adapter/attention_processor.py:238,245-246,266,1943,1957-1958,1978-1979,1998
+ *   GEGLU proj + ff.net.2   src/attentionhacked_tryon.py:656-667 (diffusers GEGLU: h*gelu(gate))
+ *   proj_in / proj_out      src/transformerhacked_tryon.py:342-346,423
+ *   ResnetBlock2D conv1/conv2/conv_shortcut/time_emb_proj, Downsample2D, Upsample2D convs
+ *                           (constructed at src/unet_block_hacked_tryon.py:1068-1079,1113-1115,2258-2269,2301)
+ *   conv_in / conv_out      src/unet_hacked_tryon.py:1245,1386 ; VAE convs (src/tryon_pipeline.py:924,1646,1876)
+ *
+ * X is a virtual [M][Ktot] matrix assembled from `nseg` K-segments.  Segment s contributes `len` (multiple of 64)
+ * consecutive k; row m = (b, oy, ox) of the OUTPUT grid reads input pixel
+ *     (iy, ix) = (oy*stride + dy, ox*stride + dx)        [>>1 each when ups=1: fused nearest-2x upsample]
+ * of the NHWC tensor `ptr` ([B][Hi][Wi][pitch]) at channels [coff, coff+len); out-of-image taps read 0.
+ * A Linear is one segment with Ho=Hi=1, Wo=Wi=M.  A 3x3 conv is 9 segments; channel-concatenated inputs
+ * (torch.cat at unet_block_hacked_tryon.py:2346,2482) are extra segments on a second pointer; the 1x1 conv_shortcut
+ * is fused as extra centre-tap segments with its weights appended along K.
+ * W is [N][Ktot] (K contiguous: nn.Linear layout; conv weights pre-permuted to [Cout][ky][kx][Cin]).
+ * Epilogue: + bias[n] + rowbias[(m / rows_per_group)*rowbias_ld + n] + res[m*ldr + n]; mode GEGLU multiplies the two
+ * 32-row halves of each 64-row weight block (weights pre-interleaved [32 h | 32 gate]) -> out has N/2 columns.
+ * Columns n >= vt_n0 (when vt != NULL) are written TRANSPOSED to vt[(b*(N-vt_n0) + n-vt_n0)*vt_tokens + tok] with
+ * (b, tok) = divmod(m, vt_tokens): the V^T layout the attention kernel consumes.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define IDMVTON_MAX_SEG 12
+typedef struct {
+    const void* ptr; /* NHWC tensor base                           */
+    uint32_t bytes;  /* size of that tensor in bytes (bounds check) */
+    int32_t pitch;   /* channels per pixel of that tensor           */
+    int32_t coff;    /* first channel read                          */
+    int32_t len;     /* channels read (multiple of 64)              */
+    int32_t dy, dx;  /* tap offset, padding already folded in       */
+} idmvton_seg;
+
+enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1 };
+typedef struct {
+    int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type) */
+    const void* w; int32_t N; int32_t Ktot;
+    int32_t nseg; idmvton_seg seg[IDMVTON_MAX_SEG];
+    int32_t M, Ho, Wo, Hi, Wi, stride, ups;
+    void* out; int32_t ldo;
+    const void* bias;
+    const void* rowbias; int32_t rowbias_ld; int32_t rows_per_group;
+    const void* res; int32_t ldr;
+    int32_t mode;
+    void* vt; int32_t vt_n0; int32_t vt_tokens;
+    int32_t tile_hint;           /* 0 = auto; else (BN<<16)|BM to force a tile (tests/bench) */
+} idmvton_gemm_conv_args;
+int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_attn_fwd : flash attention, head_dim 64, fp32 online softmax, softmax scale 1/8.
+ *
+ * Replaces F.scaled_dot_product_attention at ip_adapter/attention_processor.py:258-260 as used by
+ *   TryonNet attn1  (src/attentionhacked_tryon.py:334-348): keys = [own tokens ; garment tokens], only the first N
+ *                   query rows are computed (the reference discards rows N..2N at :348);
+ *   GarmentNet attn1 (src/attentionhacked_garmnet.py:331-342): one key segment.
+ * and the two SDPAs + sum at ip_adapter/attention_processor.py:1970-1995 (mode CROSS: out = O_text + ip_scale*O_ip).
+ *
+ * q   : [B][Nq][ldq]   head h at columns [h*64, h*64+64)
+ * k_s : [B_s][k_rows_s][ldk_s] (same head packing; first nk_s rows of each batch are keys)
+ * vt_s: V transposed, [B_s][heads*64][ldvt_s] (keys contiguous; ldvt >= roundup8(nk), columns >= nk finite)
+ * Segment s serves batches b >= seg_b0[s], reading its batch (b - seg_b0[s]).  For b < seg_b0[s] the segment's keys
+ * are the all-zero garment features of the CFG-unconditional half (src/tryon_pipeline.py:1796): K=V=0 exactly (to_k /
+ * to_v have no bias), handled in closed form as `Nk_s` keys with logit 0 and value 0.
+ * mode SELF : one softmax over all segments.   mode CROSS: segment 0 and segment 1 are separate softmaxes.
+ * ------------------------------------------------------------------------------------------------------------- */
+enum { IDMVTON_ATTN_SELF = 0, IDMVTON_ATTN_CROSS = 1 };
+typedef struct {
+    int32_t dtype; int32_t mode;
+    int32_t B, heads, Nq;
+    const void* q; int32_t ldq;
+    void* out; int32_t ldo;
+    int32_t nseg;
+    const void* k[2]; int32_t ldk[2];
+    const void* vt[2]; int32_t ldvt[2];
+    int32_t nk[2];               /* keys per segment (masked beyond nk)                          */
+    int32_t k_rows[2];           /* rows per batch element in k[s] (>= nk; 0 means nk)           */
+    int32_t seg_b0[2];
+    float ip_scale;
+} idmvton_attn_args;
+int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_layernorm : y = LN(x)*gamma+beta over the last dim, fp32 statistics (eps inside sqrt), optional second copy.
+ * Replaces nn.LayerNorm at src/attentionhacked_tryon.py:199,229,256 (eps 1e-5 :147); `y2` is the GarmentNet feature
+ * export of src/attentionhacked_garmnet.py:321-322 fused into the same pass.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype; int32_t rows, C;
+    const void* x; int32_t ldx;
+    const void* gamma; const void* beta; float eps;
+    void* y; int32_t ldy;
+    void* y2; int32_t ldy2;
+} idmvton_layernorm_args;
+int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_groupnorm : NHWC GroupNorm (+ optional SiLU), fp32/fp64 statistics.  Two launches inside one call:
+ * stats (sum, sum-of-squares per (b, group) accumulated in double) then apply.  The input may be the channel-concat
+ * of two tensors (x: C1 channels, x2: C-C1 channels) -- the torch.cat of skip connections is never materialised.
+ * Replaces nn.GroupNorm (+F.silu) in diffusers ResnetBlock2D (eps 1e-5; src/unet_hacked_tryon.py:325,606),
+ * Transformer2DModel.norm (eps 1e-6; src/transformerhacked_tryon.py:148,329), conv_norm_out (:1383-1385), VAE norms.
+ * `stats` is caller-owned scratch of B*groups*2 doubles; it is zeroed by the call (memset node on the stream).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype; int32_t B, HW, C, groups;
+    const void* x; int32_t C1;  /* channels taken from x  (== C when x2 is NULL) */
+    const void* x2;
+    const void* gamma; const void* beta; float eps; int32_t silu;
+    void* y;                    /* [B][HW][C] */
+    double* stats;
+} idmvton_groupnorm_args;
+int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Small fused elementwise ops of the loop body (src/tryon_pipeline.py:1769-1823).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* Build the TryonNet input (tryon_pipeline.py:1769,1777): NHWC [2B][hw][cpad] = cat([latents]*2 | mask | masked | pose),
+ * channels [13, cpad) zero.  latents: fp32 NCHW [B][4][hw]; cond: dtype NHWC [2B][hw][9] (step-invariant). */
+typedef struct {
+    int32_t dtype; int32_t B, hw, cpad;
+    const float* latents; const void* cond; void* out;
+} idmvton_pack_input_args;
+int idmvton_pack_input(const idmvton_pack_input_args* a, void* stream);
+
+/* CFG combine + scheduler step (tryon_pipeline.py:1814-1823; diffusers DDPMScheduler.step / DDIM eta=0):
+ * eps = e_u + g*(e_c - e_u);  latents = c_x*latents + c_eps*eps + sigma*noise.   eps_nhwc: dtype NHWC [2B][hw][ldc]
+ * (channels 0..3 used); latents/noise: fp32 NCHW [B][4][hw]; coef: DEVICE pointer to {c_x, c_eps, sigma, g}. */
+typedef struct {
+    int32_t dtype; int32_t B, hw, ldc;
+    const void* eps_nhwc; float* latents; const float* noise; const float* coef;
+} idmvton_cfg_step_args;
+int idmvton_cfg_step(const idmvton_cfg_step_args* a, void* stream);
+
+/* Layout / dtype conversion at the pipeline edges: NCHW fp32 <-> NHWC dtype with channel padding. */
+typedef struct {
+    int32_t dtype; int32_t B, C, HW, cpad; int32_t to_nhwc; /* 1: src fp32 NCHW -> dst dtype NHWC[cpad]; 0: reverse */
+    const void* src; void* dst; float scale; float shift;    /* dst = src*scale + shift */
+} idmvton_layout_args;
+int idmvton_layout(const idmvton_layout_args* a, void* stream);
+
+/* Diagonal-Gaussian posterior sample of the VAE (tryon_pipeline.py:255):
+ * z = (mean + exp(0.5*clamp(logvar,-30,20))*noise) * scale ; moments: dtype NHWC [B][hw][ldm] (mean 0..3, logvar 4..7),
+ * noise fp32 NCHW [B][4][hw], z fp32 NCHW [B][4][hw]. */
+typedef struct {
+    int32_t dtype; int32_t B, hw, ldm;
+    const void* moments; const float* noise; float* z; float scale;
+} idmvton_vae_sample_args;
+int idmvton_vae_sample(const idmvton_vae_sample_args* a, void* stream);
+
+/* Hardware layout probes (tests/test_probe_gpu.py): run one MFMA / LDS-transpose instruction on caller data. */
+int idmvton_probe_mfma(int which, const void* a, const void* b, float* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

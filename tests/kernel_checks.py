@@ -1,0 +1,304 @@
+"""Kernel-level parity checks: each C-ABI op vs a plain PyTorch fp32 reference of the same op on the same
+(dtype-rounded) inputs.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and tools/gpu_diag.py (prints every result
+instead of stopping at the first failure).
+
+Error metric everywhere: err = max|x - ref| / max|ref|  (SURVEY.md 7.3 H3).  Tolerances: fp16 storage / fp32 accumulate
+-> 2e-3; bf16 -> 1.6e-2 (one rounding of the output dominates: 2^-11 / 2^-8 relative to the value, plus accumulation).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+
+
+def relerr(x, ref):
+    x, ref = x.float(), ref.float()
+    if not torch.isfinite(x).all():
+        return float("inf")
+    return ((x - ref).abs().max() / ref.abs().max().clamp_min(1e-20)).item()
+
+
+def _r(*shape, dtype, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape) * 7919 % 100003)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------ MFMA layout probe
+def check_probe_mfma(dtype, dev):
+    """A[32][16] . B[16][32] through one MFMA; operand/result lane layouts as documented in csrc/common.cuh."""
+    from idm_vton_amd import ops
+    A = _r(32, 16, dtype=dtype, dev="cpu", seed=1)
+    Bm = _r(16, 32, dtype=dtype, dev="cpu", seed=2)       # deliberately not symmetric
+    lane = torch.arange(64)
+    ka = (8 * (lane // 32))[:, None] + torch.arange(8)[None, :]          # k index of element j in lane
+    a_frag = A[(lane % 32)[:, None], ka]                                 # A[i = lane&31][k]
+    b_frag = Bm[ka, (lane % 32)[:, None]]                                # B[k][j = lane&31]
+    c = ops.probe_mfma(0 if dtype == torch.bfloat16 else 1, a_frag.contiguous().to(dev), b_frag.contiguous().to(dev)).cpu()
+    ref = A.float() @ Bm.float()
+    r = torch.arange(16)
+    rows = (r % 4)[None, :] + 8 * (r // 4)[None, :] + 4 * (lane // 32)[:, None]   # row of reg r in lane
+    got = torch.empty(32, 32)
+    got[rows, (lane % 32)[:, None].expand(64, 16)] = c
+    return relerr(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / conv
+def check_linear(M, N, K, dtype, dev, bias=True, res=True, rowbias=False, tile_hint=0, seed=0):
+    from idm_vton_amd import ops
+    x = _r(M, K, dtype=dtype, dev=dev, seed=seed)
+    w = _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 1)
+    b = _r(N, dtype=dtype, dev=dev, seed=seed + 2) if bias else None
+    rs = _r(M, N, dtype=dtype, dev=dev, seed=seed + 3) if res else None
+    ref = x.float() @ w.float().t()
+    if bias:
+        ref = ref + b.float()
+    kw = {}
+    if rowbias:
+        G = 4 if M % 4 == 0 else 1
+        rb = _r(G, N, dtype=dtype, dev=dev, seed=seed + 4)
+        ref = ref + rb.float().repeat_interleave(M // G, dim=0)
+        kw = dict(rowbias=rb, rowbias_ld=N, rows_per_group=M // G)
+    if res:
+        ref = ref + rs.float()
+    out = ops.linear(x, w, bias=b, res=rs, tile_hint=tile_hint, **kw)
+    return relerr(out, ref)
+
+
+def check_geglu(M, C, dtype, dev, seed=0):
+    """GEGLU(x) = h * gelu(gate), [h | gate] = x W^T + b  (weights interleaved in 64-row blocks for the kernel)."""
+    from idm_vton_amd import ops
+    from idm_vton_amd.weights import interleave_geglu
+    inner = 4 * C
+    x = _r(M, C, dtype=dtype, dev=dev, seed=seed)
+    w = _r(2 * inner, C, dtype=dtype, dev=dev, scale=C ** -0.5, seed=seed + 1)
+    b = _r(2 * inner, dtype=dtype, dev=dev, seed=seed + 2)
+    y = x.float() @ w.float().t() + b.float()
+    h, g = y.chunk(2, dim=-1)
+    ref = h * F.gelu(g)
+    wi, bi = interleave_geglu(w, b)
+    out = ops.linear(x, wi, bias=bi, geglu=True)
+    return relerr(out, ref)
+
+
+def check_vt(B, Ntok, C, dtype, dev, seed=0):
+    """Fused QKV-style projection: columns [0,2C) normal, columns [2C,3C) written transposed as V^T[b][c][tok]."""
+    from idm_vton_amd import ops
+    M = B * Ntok
+    x = _r(M, C, dtype=dtype, dev=dev, seed=seed)
+    w = _r(3 * C, C, dtype=dtype, dev=dev, scale=C ** -0.5, seed=seed + 1)
+    ref = x.float() @ w.float().t()
+    out = torch.zeros(M, 2 * C, dtype=dtype, device=dev)
+    vt = torch.zeros(B, C, Ntok, dtype=dtype, device=dev)
+    ops.linear(x, w, out=out, vt=vt, vt_n0=2 * C, vt_tokens=Ntok)
+    e1 = relerr(out, ref[:, : 2 * C])
+    e2 = relerr(vt, ref[:, 2 * C:].reshape(B, Ntok, C).transpose(1, 2))
+    return max(e1, e2)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def check_conv(B, Cin, Cout, H, W, dtype, dev, k=3, stride=1, ups=False, split=0, shortcut=0, temb=False, res=False,
+               seed=0):
+    """3x3 / 1x1 conv over NHWC with the fused extras of ResnetBlock2D:
+    split>0  : input is cat([x1 (split ch), x2]) along C, never materialised (two pointers);
+    shortcut : extra 1x1 conv of a second tensor (`shortcut` channels) fused as centre-tap K segments;
+    temb     : + per-batch row vector; res: + residual; ups: nearest-2x upsample fused into the gather."""
+    from idm_vton_amd import ops
+    from idm_vton_amd.weights import conv_weight_nhwc
+    pad = (k - 1) // 2
+    x = _r(B, Cin, H, W, dtype=dtype, dev=dev, seed=seed)
+    w = _r(Cout, Cin, k, k, dtype=dtype, dev=dev, scale=(Cin * k * k) ** -0.5, seed=seed + 1)
+    bias = _r(Cout, dtype=dtype, dev=dev, seed=seed + 2)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), bias.float(), stride=stride, padding=pad)
+    Ho, Wo = ref.shape[-2:]
+    xn = _nhwc(x)
+    if split:
+        x1, x2 = xn[..., :split].contiguous(), xn[..., split:].contiguous()
+        segs = []
+        for ky in range(k):
+            for kx in range(k):
+                segs.append(ops.SegSpec(x1, 0, split, ky - pad, kx - pad))
+                segs.append(ops.SegSpec(x2, 0, Cin - split, ky - pad, kx - pad))
+    else:
+        segs = ops.conv_segs(xn, k, pad)
+    wk = conv_weight_nhwc(w)
+    kw = {}
+    if shortcut:
+        xs = _r(B, shortcut, Ho, Wo, dtype=dtype, dev=dev, seed=seed + 5)
+        ws = _r(Cout, shortcut, 1, 1, dtype=dtype, dev=dev, scale=shortcut ** -0.5, seed=seed + 6)
+        ref = ref + F.conv2d(xs.float(), ws.float())
+        xsn = _nhwc(xs)
+        segs.append(ops.SegSpec(xsn, 0, shortcut, 0, 0))
+        wk = torch.cat([wk, ws.reshape(Cout, shortcut)], dim=1).contiguous()
+        assert stride == 1 and not ups
+    M = B * Ho * Wo
+    if temb:
+        tb = _r(B, Cout, dtype=dtype, dev=dev, seed=seed + 3)
+        ref = ref + tb.float()[:, :, None, None]
+        kw.update(rowbias=tb, rowbias_ld=Cout, rows_per_group=Ho * Wo)
+    if res:
+        rs = _r(B, Cout, Ho, Wo, dtype=dtype, dev=dev, seed=seed + 4)
+        ref = ref + rs.float()
+        kw.update(res=_nhwc(rs).reshape(M, Cout))
+    if len(segs) > 12:
+        raise ValueError("too many segments for one launch")
+    out = ops.gemm_conv(segs, wk, M, Ho=Ho, Wo=Wo, Hi=H, Wi=W, stride=stride, ups=ups, bias=bias, **kw)
+    return relerr(out.reshape(B, Ho, Wo, Cout), _nhwc(ref))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0):
+    """TryonNet attn1 semantics: keys = [own N tokens ; n_garm garment tokens]; batches < b0 see all-zero garment K/V."""
+    from idm_vton_amd import ops
+    Cc = heads * 64
+    q = _r(B, N, Cc, dtype=dtype, dev=dev, scale=scale, seed=seed)
+    k1 = _r(B, N, Cc, dtype=dtype, dev=dev, scale=scale, seed=seed + 1)
+    v1 = _r(B, N, Cc, dtype=dtype, dev=dev, seed=seed + 2)
+    sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+    kk, vv = sp(k1), sp(v1)
+    segs = [dict(k=k1, vt=v1.transpose(1, 2).contiguous(), nk=N, ldk=Cc, ldvt=N)]
+    if n_garm:
+        Bg = B - b0
+        k2 = _r(Bg, n_garm, Cc, dtype=dtype, dev=dev, scale=scale, seed=seed + 3)
+        v2 = _r(Bg, n_garm, Cc, dtype=dtype, dev=dev, seed=seed + 4)
+        ld = (n_garm + 7) // 8 * 8
+        vt2 = torch.zeros(Bg, Cc, ld, dtype=dtype, device=dev)
+        vt2[:, :, :n_garm] = v2.transpose(1, 2)
+        segs.append(dict(k=k2, vt=vt2, nk=n_garm, ldk=Cc, ldvt=ld, b0=b0))
+        z = torch.zeros(b0, heads, n_garm, 64, device=dev)
+        kk = torch.cat([kk, torch.cat([z, sp(k2)], dim=0)], dim=2)
+        vv = torch.cat([vv, torch.cat([z, sp(v2)], dim=0)], dim=2)
+    ref = F.scaled_dot_product_attention(sp(q), kk, vv).transpose(1, 2).reshape(B, N, Cc)
+    out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
+    ops.attention(q, out, segs, heads)
+    return relerr(out, ref)
+
+
+def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, seed=0):
+    """IPAttnProcessor2_0 semantics: SDPA over text keys + ip_scale * SDPA over image keys."""
+    from idm_vton_amd import ops
+    Cc = heads * 64
+    q = _r(B, N, Cc, dtype=dtype, dev=dev, seed=seed)
+    sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+    segs, ref = [], 0
+    for i, (nk, sc) in enumerate(((n_text, 1.0), (n_ip, ip_scale))):
+        rows = (nk + 7) // 8 * 8
+        k = torch.zeros(B, rows, Cc, dtype=dtype, device=dev)
+        k[:, :nk] = _r(B, nk, Cc, dtype=dtype, dev=dev, seed=seed + 10 + i)
+        v = _r(B, nk, Cc, dtype=dtype, dev=dev, seed=seed + 20 + i)
+        vt = torch.zeros(B, Cc, rows, dtype=dtype, device=dev)
+        vt[:, :, :nk] = v.transpose(1, 2)
+        segs.append(dict(k=k, vt=vt, nk=nk, ldk=Cc, ldvt=rows, k_rows=rows))
+        ref = ref + sc * F.scaled_dot_product_attention(sp(q), sp(k[:, :nk]), sp(v))
+    ref = ref.transpose(1, 2).reshape(B, N, Cc)
+    out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
+    from idm_vton_amd import ffi
+    ops.attention(q, out, segs, heads, mode=ffi.ATTN_CROSS, ip_scale=ip_scale)
+    return relerr(out, ref)
+
+
+# ------------------------------------------------------------------------------------------------ norms / elementwise
+def check_layernorm(rows, Cc, dtype, dev, seed=0):
+    from idm_vton_amd import ops
+    x = _r(rows, Cc, dtype=dtype, dev=dev, scale=3.0, seed=seed) + 1.5
+    g = _r(Cc, dtype=dtype, dev=dev, seed=seed + 1)
+    b = _r(Cc, dtype=dtype, dev=dev, seed=seed + 2)
+    ref = F.layer_norm(x.float(), (Cc,), g.float(), b.float(), 1e-5)
+    o2 = torch.empty_like(x)
+    out = ops.layernorm(x, g, b, 1e-5, out2=o2)
+    return max(relerr(out, ref), relerr(o2, ref))
+
+
+def check_groupnorm(B, HW, Cc, dtype, dev, groups=32, silu=True, split=0, eps=1e-5, seed=0):
+    from idm_vton_amd import ops
+    x = _r(B, HW, Cc, dtype=dtype, dev=dev, scale=2.0, seed=seed) + 0.7
+    g = _r(Cc, dtype=dtype, dev=dev, seed=seed + 1)
+    b = _r(Cc, dtype=dtype, dev=dev, seed=seed + 2)
+    ref = F.group_norm(x.float().transpose(1, 2), groups, g.float(), b.float(), eps).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    stats = torch.empty(B * groups * 2, dtype=torch.float64, device=dev)
+    if split:
+        out = ops.groupnorm(x[..., :split].contiguous(), g, b, groups, eps, silu, stats, x2=x[..., split:].contiguous())
+    else:
+        out = ops.groupnorm(x, g, b, groups, eps, silu, stats)
+    return relerr(out, ref)
+
+
+def check_elementwise(B, h, w, dtype, dev, seed=0):
+    from idm_vton_amd import ops
+    hw = h * w
+    lat = _r(B, 4, h, w, dtype=torch.float32, dev=dev, seed=seed)
+    cond = _r(2 * B, hw, 9, dtype=dtype, dev=dev, seed=seed + 1)
+    out = torch.full((2 * B, hw, 64), 7.0, dtype=dtype, device=dev)
+    ops.pack_input(lat, cond, out)
+    ln = lat.permute(0, 2, 3, 1).reshape(B, hw, 4).to(dtype)
+    ref = torch.cat([torch.cat([ln, ln], 0), cond, torch.zeros(2 * B, hw, 51, dtype=dtype, device=dev)], dim=-1)
+    e1 = (out.float() - ref.float()).abs().max().item()
+    eps = _r(2 * B, hw, 64, dtype=dtype, dev=dev, seed=seed + 2)
+    noise = _r(B, 4, h, w, dtype=torch.float32, dev=dev, seed=seed + 3)
+    coef = torch.tensor([0.98, -0.03, 0.1, 2.0], dtype=torch.float32, device=dev)
+    e = eps[..., :4].float().reshape(2, B, h, w, 4).permute(0, 1, 4, 2, 3)
+    e = e[0] + 2.0 * (e[1] - e[0])
+    ref2 = 0.98 * lat - 0.03 * e + 0.1 * noise
+    lat2 = lat.clone()
+    ops.cfg_step(eps, lat2, noise, coef)
+    e2 = relerr(lat2, ref2)
+    src = _r(B, 3, h, w, dtype=torch.float32, dev=dev, seed=seed + 4)
+    n = ops.to_nhwc(src, dtype, cpad=64, scale=2.0, shift=-1.0)
+    back = ops.to_nchw(n, 3, (h, w), scale=0.5, shift=0.5)
+    e3 = (back - (src * 2 - 1).to(dtype).float() * 0.5 - 0.5).abs().max().item()
+    mom = _r(B, hw, 8, dtype=dtype, dev=dev, seed=seed + 5)
+    z = ops.vae_sample(mom, noise, 0.13025)
+    mm = mom.float().reshape(B, h, w, 8).permute(0, 3, 1, 2)
+    refz = (mm[:, :4] + torch.exp(0.5 * mm[:, 4:].clamp(-30, 20)) * noise) * 0.13025
+    e4 = relerr(z, refz)
+    return max(e1, e2, e3, e4)
+
+
+def all_checks(dev="cuda"):
+    """(name, thunk, tolerance) for every kernel-level check; sizes are the reference's real shapes where cheap."""
+    out = []
+    for dt in (torch.float16, torch.bfloat16):
+        n = "f16" if dt == torch.float16 else "bf16"
+        tol = TOL[dt]
+        add = lambda name, fn, t=tol: out.append((f"{name}[{n}]", fn, t))
+        add("probe_mfma", lambda dt=dt: check_probe_mfma(dt, dev), 1e-6 if dt == torch.float16 else 1e-6)
+        for hint, tag in ((0, "auto"), ((128 << 16) | 128, "128x128"), ((128 << 16) | 64, "128x64"), ((64 << 16) | 64, "64x64")):
+            add(f"linear_768x640x640_{tag}", lambda dt=dt, hint=hint: check_linear(768, 640, 640, dt, dev, tile_hint=hint))
+        add("linear_ragged_200x328x192", lambda dt=dt: check_linear(200, 328, 192, dt, dev, rowbias=True))
+        add("linear_M4_temb", lambda dt=dt: check_linear(4, 1280, 1280, dt, dev, res=False))
+        add("linear_3072x1280x1280", lambda dt=dt: check_linear(3072, 1280, 1280, dt, dev))
+        add("linear_crossKV_308x640x2048", lambda dt=dt: check_linear(308, 640, 2048, dt, dev, bias=False, res=False))
+        add("geglu_1536x640", lambda dt=dt: check_geglu(1536, 640, dt, dev))
+        add("geglu_ragged_200x64", lambda dt=dt: check_geglu(200, 64, dt, dev))
+        add("vt_qkv_B2_N768_C640", lambda dt=dt: check_vt(2, 768, 640, dt, dev))
+        add("vt_qkv_B3_N64_C128", lambda dt=dt: check_vt(3, 64, 128, dt, dev))
+        add("conv3x3_320_32x24", lambda dt=dt: check_conv(2, 320, 320, 32, 24, dt, dev, temb=True))
+        add("conv3x3_s2_128_17x13", lambda dt=dt: check_conv(2, 128, 192, 17, 13, dt, dev, stride=2))
+        add("conv3x3_ups_128_9x7", lambda dt=dt: check_conv(2, 128, 128, 9, 7, dt, dev, ups=True))
+        add("conv1x1_split_192+128", lambda dt=dt: check_conv(2, 320, 64, 12, 10, dt, dev, k=1, split=192))
+        add("conv3x3_shortcut_res", lambda dt=dt: check_conv(2, 128, 128, 16, 12, dt, dev, shortcut=192, temb=True))
+        add("conv3x3_res", lambda dt=dt: check_conv(1, 64, 64, 8, 8, dt, dev, res=True))
+        add("attn_self_1seg_N768", lambda dt=dt: check_attn_self(2, 4, 768, dt, dev))
+        add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
+        add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))
+        add("attn_self_big_logits", lambda dt=dt: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0))
+        add("attn_self_N3072_h10", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2))
+        add("attn_self_N16", lambda dt=dt: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1))
+        add("attn_cross_77_16_N768", lambda dt=dt: check_attn_cross(4, 4, 768, dt, dev))
+        add("attn_cross_scale0.5_N200", lambda dt=dt: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5))
+        add("layernorm_640", lambda dt=dt: check_layernorm(1000, 640, dt, dev))
+        add("layernorm_1280", lambda dt=dt: check_layernorm(3072, 1280, dt, dev))
+        add("layernorm_64", lambda dt=dt: check_layernorm(37, 64, dt, dev))
+        add("groupnorm_320_silu", lambda dt=dt: check_groupnorm(2, 768, 320, dt, dev))
+        add("groupnorm_1920_split1280", lambda dt=dt: check_groupnorm(2, 300, 1920, dt, dev, split=1280))
+        add("groupnorm_2560_split1280", lambda dt=dt: check_groupnorm(2, 192, 2560, dt, dev, split=1280))
+        add("groupnorm_128_nosilu_eps1e-6", lambda dt=dt: check_groupnorm(1, 4096, 128, dt, dev, silu=False, eps=1e-6))
+        add("elementwise", lambda dt=dt: check_elementwise(2, 16, 12, dt, dev))
+    return out
