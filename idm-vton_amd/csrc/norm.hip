@@ -5,7 +5,7 @@
 #include "common.cuh"
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave per row; lane l owns 8-element chunks l, l+64, l+128 (C <= 1536).  16-byte loads, fp32 math.
+// One wave per row; lane l owns 8-element chunks l, l+64, l+128, l+192 (C <= 2048).  16-byte loads, fp32 math.
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_args a) {
     typedef typename VT<T>::v8 v8;
@@ -64,7 +64,8 @@ static int launch_ln(const idmvton_layernorm_args& a, hipStream_t st) {
     const int nch = ((a.C >> 3) + 63) / 64;
     if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, a);
     else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, st, a);
+    else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, st, a);
     CHECK_LAUNCH("layernorm");
     return IDMVTON_OK;
 }
@@ -72,7 +73,7 @@ static int launch_ln(const idmvton_layernorm_args& a, hipStream_t st) {
 extern "C" int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream) {
     CHECK_ARG(a != nullptr, IDMVTON_E_ARG, "layernorm: null args");
     CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "layernorm: dtype %d", a->dtype);
-    CHECK_ARG(a->rows > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 1536, IDMVTON_E_SHAPE, "layernorm: rows=%d C=%d (C%%8==0, C<=1536)", a->rows, a->C);
+    CHECK_ARG(a->rows > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 2048, IDMVTON_E_SHAPE, "layernorm: rows=%d C=%d (C%%8==0, C<=2048)", a->rows, a->C);
     CHECK_ARG(a->x && a->y && a->gamma && a->beta, IDMVTON_E_ARG, "layernorm: null pointer");
     CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && (!a->y2 || a->ldy2 % 8 == 0), IDMVTON_E_ALIGN, "layernorm: ld alignment");
     CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->y2 | (uintptr_t)a->gamma | (uintptr_t)a->beta) & 15) == 0,
@@ -199,4 +200,57 @@ extern "C" int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream) 
     CHECK_ARG(a->C1 > 0 && a->C1 <= a->C && a->C1 % 8 == 0 && (a->C1 == a->C || a->x2), IDMVTON_E_SHAPE, "groupnorm: C1=%d", a->C1);
     CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->x2 | (uintptr_t)a->y) & 15) == 0, IDMVTON_E_ALIGN, "groupnorm: pointer alignment");
     return a->dtype == IDMVTON_BF16 ? launch_gn<bf16_t>(*a, (hipStream_t)stream) : launch_gn<f16_t>(*a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ row softmax
+// In-place softmax(scale * x) over rows of n elements (n % 8 == 0), fp32 statistics, one workgroup per row.
+// Used by the VAE mid-block attention (single head, d = 512: unet_block_hacked_tryon.py:585-597, upcast_softmax=True).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, float scale) {
+    typedef typename VT<T>::v8 v8;
+    __shared__ float red[8];
+    T* row = x + (size_t)blockIdx.x * ld;
+    const int nchunk = n >> 3;
+    const float sl = scale * 1.44269504088896341f;
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const v8 t = *(const v8*)(row + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)t[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const v8 t = *(const v8*)(row + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f(((float)t[j] - mx) * sl);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const v8 t = *(const v8*)(row + c * 8);
+        v8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (T)(__builtin_amdgcn_exp2f(((float)t[j] - mx) * sl) * inv);
+        *(v8*)(row + c * 8) = o;
+    }
+}
+
+extern "C" int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream) {
+    CHECK_ARG(a && a->x, IDMVTON_E_ARG, "softmax_rows: null pointer");
+    CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "softmax_rows: dtype %d", a->dtype);
+    CHECK_ARG(a->rows > 0 && a->n > 0 && a->n % 8 == 0 && a->ld % 8 == 0 && a->ld >= a->n && ((uintptr_t)a->x & 15) == 0,
+              IDMVTON_E_SHAPE, "softmax_rows: rows=%d n=%d ld=%d", a->rows, a->n, a->ld);
+    const dim3 grid(a->rows), block(256);
+    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)a->x, a->n, a->ld, a->scale);
+    else hipLaunchKernelGGL((softmax_rows_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (f16_t*)a->x, a->n, a->ld, a->scale);
+    CHECK_LAUNCH("softmax_rows");
+    return IDMVTON_OK;
 }

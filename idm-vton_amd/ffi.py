@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidmvton_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
-EPI_NONE, EPI_GEGLU = 0, 1
+EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
 ATTN_SELF, ATTN_CROSS = 0, 1
 MAX_SEG = 12
 
@@ -64,15 +64,19 @@ class VaeSampleArgs(C.Structure):
                 ("scale", f32)]
 
 
+class SoftmaxArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32)]
+
+
 STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_attn_args": AttnArgs,
            "idmvton_layernorm_args": LayerNormArgs, "idmvton_groupnorm_args": GroupNormArgs,
            "idmvton_pack_input_args": PackInputArgs, "idmvton_cfg_step_args": CfgStepArgs,
-           "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs}
+           "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs, "idmvton_softmax_args": SoftmaxArgs}
 
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
-           "idmvton_vae_sample", "idmvton_probe_mfma"]
+           "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma"]
 
 _lib = None
 
@@ -100,7 +104,7 @@ def lib():
         if n != C.sizeof(st):
             raise HipLibraryMissing(f"ABI drift: sizeof({name}) is {n} in the library, {C.sizeof(st)} in ffi.py")
     for s in ("idmvton_gemm_conv", "idmvton_attn_fwd", "idmvton_layernorm", "idmvton_groupnorm",
-              "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout", "idmvton_vae_sample"):
+              "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout", "idmvton_vae_sample", "idmvton_softmax_rows"):
         getattr(L, s).argtypes = [vp, vp]
         getattr(L, s).restype = C.c_int
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]

@@ -42,8 +42,8 @@ class SegSpec:
 
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
-              rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, vt=None, vt_n0=0,
-              vt_tokens=0, tile_hint=0):
+              rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, vt=None,
+              vt_n0=0, vt_tokens=0, tile_hint=0):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous."""
     a = ffi.GemmConvArgs()
     a.dtype = _dt(w)
@@ -67,7 +67,7 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.rowbias, a.rowbias_ld, a.rows_per_group = _ptr(rowbias), rowbias_ld, rows_per_group
     a.res = _ptr(res)
     a.ldr = (ldr if ldr is not None else (res.stride(-2) if res is not None else 0))
-    a.mode = ffi.EPI_GEGLU if geglu else ffi.EPI_NONE
+    a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else ffi.EPI_NONE)
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.tile_hint = tile_hint
     ffi.call("idmvton_gemm_conv", a, _stream())
@@ -187,6 +187,15 @@ def vae_sample(moments_nhwc, noise, scale, out=None):
     a.moments, a.noise, a.z, a.scale = _ptr(moments_nhwc), _ptr(noise), _ptr(out), scale
     ffi.call("idmvton_vae_sample", a, _stream())
     return out
+
+
+def softmax_rows(x, scale):
+    """In-place softmax(scale * x) over the last dim of a 2-D tensor."""
+    a = ffi.SoftmaxArgs()
+    a.dtype, a.rows, a.n, a.ld = _dt(x), x.shape[0], x.shape[1], x.stride(0)
+    a.x, a.scale = _ptr(x), scale
+    ffi.call("idmvton_softmax_rows", a, _stream())
+    return x
 
 
 def probe_mfma(which, a, b):

@@ -1,0 +1,309 @@
+"""TryonNet / GarmentNet executed on the HIP kernels (NHWC, token-major, no layout transposes anywhere).
+
+Host-side mirror of /root/reference/src/unet_hacked_tryon.py:1006-1395 and src/unet_hacked_garmnet.py:917-1284: same
+topology walk, same state-dict keys, every arithmetic op a C-ABI call (ops.py).  Exact savings taken:
+
+  * self-attention computes only the N kept query rows (reference discards rows N..2N, attentionhacked_tryon.py:348);
+  * the CFG-unconditional half's all-zero garment features (tryon_pipeline.py:1796) are never materialised: the
+    attention kernel adds their closed-form contribution (N keys, logit 0, value 0);
+  * skip-connection torch.cat's (unet_block_hacked_tryon.py:2346,2482) are dual-pointer reads;
+  * text / image-token K and V of every attn2 and add_embedding are step-invariant: projected once per call;
+  * GarmentNet stops after its last exported norm1 (everything after it is dead: unet_hacked_garmnet.py:1267-1284).
+"""
+import math
+
+import torch
+
+from . import ffi, ops
+from .config import UNetConfig, unet_topology
+from .weights import conv_weight_nhwc, conv_weight_nhwc_padded, interleave_geglu
+
+
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+class _Conv:
+    """Prepared conv: GEMM weight [Cout][taps*Cin_pad (+ shortcut Cin)] and bias (fp16/bf16)."""
+
+    def __init__(self, sd, name, cin_pad=None, shortcut=None, pad_out_to=None):
+        w = sd[name + ".weight"]
+        b = sd[name + ".bias"]
+        self.k = w.shape[-1]
+        self.cin = w.shape[1]
+        self.cin_pad = cin_pad or self.cin
+        wk = conv_weight_nhwc_padded(w, self.cin_pad) if self.cin_pad != self.cin else conv_weight_nhwc(w)
+        if shortcut is not None:                      # fused 1x1 conv_shortcut: extra K columns, biases add
+            ws = sd[shortcut + ".weight"]
+            wk = torch.cat([wk, ws.reshape(ws.shape[0], ws.shape[1])], dim=1)
+            b = (b.float() + sd[shortcut + ".bias"].float()).to(b.dtype)
+        self.cout = w.shape[0]
+        if pad_out_to and pad_out_to > self.cout:     # N must be a multiple of 4
+            wk = torch.cat([wk, torch.zeros(pad_out_to - self.cout, wk.shape[1], dtype=wk.dtype, device=wk.device)])
+            b = torch.cat([b, torch.zeros(pad_out_to - self.cout, dtype=b.dtype, device=b.device)])
+        self.w = wk.contiguous()
+        self.b = b.contiguous()
+        self.n = self.w.shape[0]
+
+
+class HipUNet:
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.topo = unet_topology(cfg)
+        sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items() if not k.startswith("encoder_hid_proj.")}
+        self.sd = sd
+        for h, c in zip(cfg.num_attention_heads, cfg.block_out_channels):
+            assert c % 64 == 0 and (c // h == 64), "HIP attention kernels are specialised for head_dim 64"
+        self.tryon = cfg.mode == "tryon"
+        self.cin_pad = _pad64(cfg.in_channels)
+        self._prep()
+        self._gn_stats = torch.empty(64 * 64 * 2, dtype=torch.float64, device=self.device)
+        self._ctx = None
+
+    # ------------------------------------------------------------------------------------------------ weight prep
+    def _prep(self):
+        sd, cfg = self.sd, self.cfg
+        self.conv_in = _Conv(sd, "conv_in", cin_pad=self.cin_pad)
+        self.res = {}
+        self.tf = {}
+        temb_w, temb_b, self.temb_slices, off = [], [], {}, 0
+
+        def prep_res(p, cin, cout):
+            sc = p + ".conv_shortcut" if cin != cout else None
+            self.res[p] = dict(conv1=_Conv(sd, p + ".conv1"), conv2=_Conv(sd, p + ".conv2", shortcut=sc), cin=cin, cout=cout)
+            nonlocal off
+            temb_w.append(sd[p + ".time_emb_proj.weight"])
+            temb_b.append(sd[p + ".time_emb_proj.bias"])
+            self.temb_slices[p] = (off, cout)
+            off += cout
+
+        def prep_tf(p, ch, n_tf, heads):
+            blocks = []
+            for k in range(n_tf):
+                b = f"{p}.transformer_blocks.{k}"
+                d = dict(heads=heads)
+                d["qkv"] = torch.cat([sd[f"{b}.attn1.to_q.weight"], sd[f"{b}.attn1.to_k.weight"], sd[f"{b}.attn1.to_v.weight"]]).contiguous()
+                d["kv_text"] = torch.cat([sd[f"{b}.attn2.to_k.weight"], sd[f"{b}.attn2.to_v.weight"]]).contiguous()
+                if self.tryon:
+                    d["kv_ip"] = torch.cat([sd[f"{b}.attn2.processor.to_k_ip.weight"], sd[f"{b}.attn2.processor.to_v_ip.weight"]]).contiguous()
+                d["ff1_w"], d["ff1_b"] = interleave_geglu(sd[f"{b}.ff.net.0.proj.weight"], sd[f"{b}.ff.net.0.proj.bias"])
+                d["p"] = b
+                blocks.append(d)
+            self.tf[p] = dict(blocks=blocks, ch=ch, heads=heads)
+
+        for i, blk in enumerate(self.topo["down"]):
+            for j, (ci, co) in enumerate(blk["resnets"]):
+                prep_res(f"down_blocks.{i}.resnets.{j}", ci, co)
+                if blk["attn"]:
+                    prep_tf(f"down_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"])
+            if blk["down"]:
+                self.res[f"down_blocks.{i}.downsamplers.0.conv"] = _Conv(sd, f"down_blocks.{i}.downsamplers.0.conv")
+        m = self.topo["mid"]
+        prep_res("mid_block.resnets.0", m["ch"], m["ch"])
+        prep_tf("mid_block.attentions.0", m["ch"], m["n_tf"], m["heads"])
+        prep_res("mid_block.resnets.1", m["ch"], m["ch"])
+        for i, blk in enumerate(self.topo["up"]):
+            if not self.tryon and not blk["attn"]:
+                continue                               # GarmentNet never executes non-attention up blocks
+            for j, (rin, skip, co) in enumerate(blk["resnets"]):
+                prep_res(f"up_blocks.{i}.resnets.{j}", rin + skip, co)
+                if blk["attn"]:
+                    prep_tf(f"up_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"])
+            if blk["up"]:
+                self.res[f"up_blocks.{i}.upsamplers.0.conv"] = _Conv(sd, f"up_blocks.{i}.upsamplers.0.conv")
+        self.temb_w = torch.cat(temb_w).contiguous()          # one GEMM for every resnet's time_emb_proj
+        self.temb_b = torch.cat(temb_b).contiguous()
+        if self.tryon:
+            self.conv_out = _Conv(sd, "conv_out", pad_out_to=_pad64(cfg.out_channels) if cfg.out_channels % 4 else None)
+
+    # ------------------------------------------------------------------------------------------------ per-call setup
+    def time_embeddings(self, timesteps, batch, added_cond=None):
+        """emb[step] = time_embedding(Timesteps(t)) (+ add_embedding(...)), then EVERY resnet's time_emb_proj(silu(emb))
+        in one GEMM per step (unet_hacked_tryon.py:1118-1213; diffusers ResnetBlock2D).  Returns [steps][batch][sum Cout].
+        Runs once per pipeline call, outside the denoising loop (the timestep schedule is known up front)."""
+        cfg, sd, dt = self.cfg, self.sd, self.dtype
+        ts = torch.as_tensor(timesteps, dtype=torch.float32, device=self.device).reshape(-1)
+        half = cfg.block_out_channels[0] // 2
+        freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=self.device) / half)
+        ang = ts[:, None] * freq[None, :]
+        t_emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(dt)            # flip_sin_to_cos
+        S = ts.numel()
+        mp = max(S, 1)
+        e = ops.linear(t_emb.contiguous(), sd["time_embedding.linear_1.weight"], bias=sd["time_embedding.linear_1.bias"])
+        e = ops.linear(torch.nn.functional.silu(e.float()).to(dt), sd["time_embedding.linear_2.weight"], bias=sd["time_embedding.linear_2.bias"])
+        emb = e[:, None, :].expand(S, batch, -1)                                        # timesteps.expand(batch)
+        if cfg.addition_embed_type == "text_time":
+            text_embeds, time_ids = added_cond["text_embeds"], added_cond["time_ids"]
+            h2 = cfg.addition_time_embed_dim // 2
+            f2 = torch.exp(-math.log(10000.0) * torch.arange(h2, dtype=torch.float32, device=self.device) / h2)
+            a2 = time_ids.to(self.device).float().flatten()[:, None] * f2[None, :]
+            te = torch.cat([torch.cos(a2), torch.sin(a2)], dim=-1).reshape(batch, -1)
+            add = torch.cat([text_embeds.to(self.device).float(), te], dim=-1).to(dt).contiguous()
+            a = ops.linear(add, sd["add_embedding.linear_1.weight"], bias=sd["add_embedding.linear_1.bias"])
+            a = ops.linear(torch.nn.functional.silu(a.float()).to(dt), sd["add_embedding.linear_2.weight"], bias=sd["add_embedding.linear_2.bias"])
+            emb = (emb.float() + a.float()[None]).to(dt)
+        x = torch.nn.functional.silu(emb.float()).to(dt).reshape(S * batch, -1).contiguous()
+        out = ops.linear(x, self.temb_w, bias=self.temb_b)
+        return out.reshape(S, batch, -1)
+
+    def encode_context(self, text, ip=None):
+        """Step-invariant cross-attention K / V^T for every attn2 (ip_adapter/attention_processor.py:1957-1958,1978-1979).
+        text: [B][77][xd]; ip: [B][16][xd] image tokens (TryonNet).  Rows are padded to a multiple of 8 with zeros."""
+        dt, dev = self.dtype, self.device
+        B, nt, xd = text.shape
+        rt = (nt + 7) // 8 * 8
+        tpad = torch.zeros(B, rt, xd, dtype=dt, device=dev)
+        tpad[:, :nt] = text.to(dev, dt)
+        ctx = dict(B=B, nt=nt, rt=rt, kv={})
+        if ip is not None:
+            ni = ip.shape[1]
+            ri = (ni + 7) // 8 * 8
+            ipad = torch.zeros(B, ri, xd, dtype=dt, device=dev)
+            ipad[:, :ni] = ip.to(dev, dt)
+            ctx.update(ni=ni, ri=ri)
+        for p, tf in self.tf.items():
+            C = tf["ch"]
+            for blk in tf["blocks"]:
+                kt = torch.empty(B * rt, C, dtype=dt, device=dev)
+                vtt = torch.empty(B, C, rt, dtype=dt, device=dev)
+                ops.linear(tpad.reshape(B * rt, xd), blk["kv_text"], out=kt, vt=vtt, vt_n0=C, vt_tokens=rt)
+                ent = dict(kt=kt, vtt=vtt)
+                if ip is not None:
+                    ki = torch.empty(B * ri, C, dtype=dt, device=dev)
+                    vti = torch.empty(B, C, ri, dtype=dt, device=dev)
+                    ops.linear(ipad.reshape(B * ri, xd), blk["kv_ip"], out=ki, vt=vti, vt_n0=C, vt_tokens=ri)
+                    ent.update(ki=ki, vti=vti)
+                ctx["kv"][blk["p"]] = ent
+        return ctx
+
+    # ------------------------------------------------------------------------------------------------ building blocks
+    def _gn(self, xa, xb, name, eps, silu):
+        sd = self.sd
+        return ops.groupnorm(xa, sd[name + ".weight"], sd[name + ".bias"], self.cfg.norm_num_groups, eps, silu,
+                             self._gn_stats, x2=xb)
+
+    def _conv3(self, x, cv, B, H, W, stride=1, ups=False, extra_segs=(), **kw):
+        Ho, Wo = (H * 2, W * 2) if ups else ((H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1)
+        segs = ops.conv_segs(x, 3, 1, length=cv.cin_pad) + list(extra_segs)
+        out = ops.gemm_conv(segs, cv.w, B * Ho * Wo, Ho=Ho, Wo=Wo, Hi=H, Wi=W, stride=stride, ups=ups, bias=cv.b, **kw)
+        return out.view(B, Ho * Wo, cv.n), Ho, Wo
+
+    def _resnet(self, p, xa, xb, temb, B, H, W):
+        """diffusers ResnetBlock2D.  xa (+xb): input, virtually concatenated along channels."""
+        r = self.res[p]
+        eps = self.cfg.norm_eps
+        g1 = self._gn(xa, xb, p + ".norm1", eps, True)
+        off, co = self.temb_slices[p]
+        h, _, _ = self._conv3(g1, r["conv1"], B, H, W, rowbias=temb[:, off:off + co], rowbias_ld=temb.stride(0),
+                              rows_per_group=H * W)
+        g2 = self._gn(h, None, p + ".norm2", eps, True)
+        if r["cin"] != r["cout"]:                    # 1x1 conv_shortcut fused as extra centre-tap K segments
+            extra = [ops.SegSpec(xa, 0, xa.shape[-1])] + ([ops.SegSpec(xb, 0, xb.shape[-1])] if xb is not None else [])
+            out, _, _ = self._conv3(g2, r["conv2"], B, H, W, extra_segs=extra)
+        else:
+            out, _, _ = self._conv3(g2, r["conv2"], B, H, W, res=xa.reshape(B * H * W, -1))
+        return out
+
+    def _block(self, blk, hs, B, N, C, ctx, garment, feats_out, stop=None):
+        """BasicTransformerBlock: tryon src/attentionhacked_tryon.py:284-415, garmnet src/attentionhacked_garmnet.py:284-406."""
+        sd, p, heads = self.sd, blk["p"], blk["heads"]
+        dt, dev = self.dtype, self.device
+        M = B * N
+        feat = None
+        if not self.tryon:
+            feat = torch.empty(M, C, dtype=dt, device=dev)      # exported norm1 output (garmnet :321-322)
+        n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
+        if feat is not None:
+            feats_out.append(feat.view(B, N, C))
+            if stop is not None and len(feats_out) >= stop:
+                return None                              # GarmentNet: everything after the last export is dead compute
+        qk = torch.empty(M, 2 * C, dtype=dt, device=dev)
+        vt = torch.empty(B, C, N, dtype=dt, device=dev)
+        ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N)
+        segs = [dict(k=qk[:, C:], vt=vt, nk=N, ldk=2 * C, ldvt=N)]
+        if self.tryon:
+            g = garment["feats"][garment["idx"]]                # [Bg][N][C]
+            garment["idx"] += 1
+            Bg = g.shape[0]
+            kg = torch.empty(Bg * N, C, dtype=dt, device=dev)
+            vtg = torch.empty(Bg, C, N, dtype=dt, device=dev)
+            ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
+            segs.append(dict(k=kg, vt=vtg, nk=N, ldk=C, ldvt=N, b0=B - Bg))
+        att = torch.empty(M, C, dtype=dt, device=dev)
+        ops.attention(qk, att, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C)
+        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs)
+        # cross attention
+        n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+        q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
+        kv = ctx["kv"][p]
+        att2 = torch.empty(M, C, dtype=dt, device=dev)
+        seg_t = dict(k=kv["kt"], vt=kv["vtt"], nk=ctx["nt"], ldk=C, ldvt=ctx["rt"], k_rows=ctx["rt"])
+        if self.tryon:
+            seg_i = dict(k=kv["ki"], vt=kv["vti"], nk=ctx["ni"], ldk=C, ldvt=ctx["ri"], k_rows=ctx["ri"])
+            ops.attention(q2, att2, [seg_t, seg_i], heads, mode=ffi.ATTN_CROSS, ip_scale=1.0, B=B, Nq=N, ldq=C, ldo=C)
+        else:
+            ops.attention(q2, att2, [seg_t], heads, B=B, Nq=N, ldq=C, ldo=C)
+        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs)
+        # feed-forward (GEGLU fused into the first GEMM's epilogue)
+        n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
+        gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
+        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs)
+        return hs
+
+    def _transformer(self, p, x, B, H, W, ctx, garment, feats_out, stop_after_feats=None):
+        """Transformer2DModel (src/transformerhacked_tryon.py:246-467), NHWC so no permutes."""
+        sd, tf = self.sd, self.tf[p]
+        C, N = tf["ch"], H * W
+        g = self._gn(x, None, p + ".norm", 1e-6, False)
+        hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"])
+        for blk in tf["blocks"]:
+            hs = self._block(blk, hs, B, N, C, ctx, garment, feats_out, stop_after_feats)
+            if hs is None:
+                return None
+        out = ops.linear(hs, sd[p + ".proj_out.weight"], bias=sd[p + ".proj_out.bias"], res=x.reshape(B * N, C))
+        return out.view(B, N, C)
+
+    def num_features(self):
+        return sum(len(t["blocks"]) for t in self.tf.values())
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x, temb, ctx, B, H, W, garment_feats=None):
+        """x: NHWC [B][H*W][cin_pad] (channels >= in_channels zero); temb: [B][sum Cout] (time_embeddings()[step]);
+        ctx: encode_context(); garment_feats: list of [Bg][N][C] (Bg <= B; batches < B-Bg see all-zero features).
+        Returns (noise NHWC [B][H*W][n_out] for TryonNet | None, exported features for GarmentNet)."""
+        topo = self.topo
+        garment = dict(feats=garment_feats, idx=0)
+        feats = []
+        stop = None if self.tryon else self.num_features()
+        h, _, _ = self._conv3(x, self.conv_in, B, H, W)
+        skips = [(h, H, W)]
+        for i, blk in enumerate(topo["down"]):
+            for j in range(len(blk["resnets"])):
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, None, temb, B, H, W)
+                if blk["attn"]:
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, B, H, W, ctx, garment, feats)
+                skips.append((h, H, W))
+            if blk["down"]:
+                h, H, W = self._conv3(h, self.res[f"down_blocks.{i}.downsamplers.0.conv"], B, H, W, stride=2)
+                skips.append((h, H, W))
+        h = self._resnet("mid_block.resnets.0", h, None, temb, B, H, W)
+        h = self._transformer("mid_block.attentions.0", h, B, H, W, ctx, garment, feats)
+        h = self._resnet("mid_block.resnets.1", h, None, temb, B, H, W)
+        for i, blk in enumerate(topo["up"]):
+            if not self.tryon and not blk["attn"]:
+                continue
+            for j in range(len(blk["resnets"])):
+                s, sh, sw = skips.pop()
+                assert (sh, sw) == (H, W), "skip/upsample size mismatch (H, W must be multiples of 2^num_upsamplers)"
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", h, s, temb, B, H, W)
+                if blk["attn"]:
+                    h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, B, H, W, ctx, garment, feats, stop)
+                    if h is None:
+                        return None, feats
+            if blk["up"]:
+                h, H, W = self._conv3(h, self.res[f"up_blocks.{i}.upsamplers.0.conv"], B, H, W, ups=True)
+        if not self.tryon:
+            return None, feats
+        g = self._gn(h, None, "conv_norm_out", self.cfg.norm_eps, True)
+        out, _, _ = self._conv3(g, self.conv_out, B, H, W)
+        return out, feats

@@ -61,7 +61,7 @@ typedef struct {
     int32_t dy, dx;  /* tap offset, padding already folded in       */
 } idmvton_seg;
 
-enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1 };
+enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1, IDMVTON_EPI_GELU = 2 /* gelu_erf(acc+bias+rowbias) then +res */ };
 typedef struct {
     int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type) */
     const void* w; int32_t N; int32_t Ktot;
@@ -177,6 +177,14 @@ typedef struct {
     const void* moments; const float* noise; float* z; float scale;
 } idmvton_vae_sample_args;
 int idmvton_vae_sample(const idmvton_vae_sample_args* a, void* stream);
+
+/* In-place row softmax(scale*x), fp32 statistics.  VAE mid-block attention (1 head x 512:
+ * src/unet_block_hacked_tryon.py:585-597, upcast_softmax=True) = gemm_conv (QK^T) + softmax_rows + gemm_conv (PV). */
+typedef struct {
+    int32_t dtype; int32_t rows, n, ld;
+    void* x; float scale;
+} idmvton_softmax_args;
+int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream);
 
 /* Hardware layout probes (tests/test_probe_gpu.py): run one MFMA / LDS-transpose instruction on caller data. */
 int idmvton_probe_mfma(int which, const void* a, const void* b, float* c, void* stream);

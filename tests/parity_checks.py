@@ -1,0 +1,84 @@
+"""Model-level parity: HIP engine (GPU) vs oracle (CPU fp32) on identical weights / inputs / noise.
+Returns a dict of max-rel errors per stage; used by tests/test_parity_gpu.py and tools/gpu_parity.py."""
+import torch
+
+from tests import parity_utils as pu
+
+
+@torch.no_grad()
+def run(kind="tiny", dtype=torch.float16, B=1, H=128, W=128, steps=4, scheduler="ddpm", use_graph=False, device="cuda"):
+    from idm_vton_amd import ops
+    from idm_vton_amd.pipeline import TryonEngine
+    from oracle import pipeline as opipe
+    from oracle.scheduler import Scheduler
+
+    m = pu.build(kind, dtype, device)
+    o_t, o_g, o_v = m["oracle"]
+    p_t, p_g, p_v, p_r = m["product"]
+    inp = pu.make_inputs(B, H, W, m["xd"], m["pooled"], m["enc_dim"], steps, dtype)
+    h, w = H // 8, W // 8
+    res = {}
+
+    # ---- A: Resampler (plugin API: unet.encoder_hid_proj) ----
+    ie_o = o_t.encoder_hid_proj(inp["ip_hidden_states"])
+    ie_p = p_r(inp["ip_hidden_states"])
+    res["resampler"] = pu.relerr(ie_p, ie_o)
+
+    # ---- B: VAE encode / decode ----
+    img = inp["cloth"]
+    z_o = o_v.encode_sample(img, inp["noise"]["cloth"]) * o_v.cfg.scaling_factor
+    z_p = p_v.encode_sample(img.to(device), inp["noise"]["cloth"].to(device))
+    res["vae_encode"] = pu.relerr(z_p, z_o)
+    d_o = o_v.decode(z_o / o_v.cfg.scaling_factor)
+    d_p = p_v.decode(z_o.to(device) / o_v.cfg.scaling_factor)
+    res["vae_decode"] = pu.relerr(d_p, d_o)
+
+    # ---- C: GarmentNet features (same latent in) ----
+    t = 481
+    _, f_o = o_g(z_o, t, inp["text_embeds_cloth"])
+    ctx_g = p_g.encode_context(inp["text_embeds_cloth"].to(device))
+    temb_g = p_g.time_embeddings([t], B)[0]
+    x_g = ops.to_nhwc(z_o.to(device).float().contiguous(), dtype, cpad=p_g.cin_pad)
+    _, f_p = p_g.forward(x_g, temb_g, ctx_g, B, h, w)
+    assert len(f_o) == len(f_p) == p_g.num_features()
+    errs = [pu.relerr(a, b) for a, b in zip(f_p, f_o)]
+    res["garment_feat_first"], res["garment_feat_last"], res["garment_feat_max"] = errs[0], errs[-1], max(errs)
+
+    # ---- D: TryonNet noise prediction (oracle's features in, CFG batch) ----
+    g = torch.Generator().manual_seed(7)
+    lmi = torch.randn(2 * B, 13, h, w, generator=g)
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    add_text = torch.cat([inp["negative_pooled_prompt_embeds"], inp["pooled_prompt_embeds"]])
+    time_ids = torch.tensor([[H, W, 0, 0, H, W]], dtype=torch.float32).repeat(2 * B, 1)
+    added = dict(text_embeds=add_text, time_ids=time_ids, image_embeds=ie_o)
+    feats_cfg = [torch.cat([torch.zeros_like(d), d]) for d in f_o]
+    eps_o = o_t(lmi, t, pe, added_cond_kwargs=added, garment_features=feats_cfg)[0]
+    ctx_t = p_t.encode_context(pe.to(device), ie_o.to(device))
+    temb_t = p_t.time_embeddings([t], 2 * B, dict(text_embeds=add_text.to(device), time_ids=time_ids.to(device)))[0]
+    x_t = ops.to_nhwc(lmi.to(device).contiguous(), dtype, cpad=p_t.cin_pad)
+    feats_dev = [d.to(device, dtype).contiguous() for d in f_o]
+    eps_p, _ = p_t.forward(x_t, temb_t, ctx_t, 2 * B, h, w, garment_feats=feats_dev)
+    eps_p = eps_p.view(2 * B, h, w, -1)[..., :4].permute(0, 3, 1, 2)
+    res["tryon_eps"] = pu.relerr(eps_p, eps_o)
+    # the same with the zero half materialised (general garment_features= API path, no closed form)
+    feats_full = [d.to(device, dtype).contiguous() for d in feats_cfg]
+    eps_p2, _ = p_t.forward(x_t, temb_t, ctx_t, 2 * B, h, w, garment_feats=feats_full)
+    eps_p2 = eps_p2.view(2 * B, h, w, -1)[..., :4].permute(0, 3, 1, 2)
+    res["tryon_eps_materialised_zeros"] = pu.relerr(eps_p2, eps_o)
+    res["closed_form_vs_materialised"] = pu.relerr(eps_p, eps_p2)
+
+    # ---- E: whole pipeline, injected noise ----
+    tr = {}
+    img_o = opipe.run(o_t, o_g, o_v, Scheduler(scheduler), num_inference_steps=steps, guidance_scale=2.0, trace=tr, **inp)
+    eng = TryonEngine(p_t, p_g, p_v, p_r, dtype, device)
+    st = eng.prepare(num_inference_steps=steps, guidance_scale=2.0, scheduler=scheduler, **inp)
+    res["prep_masked_lat"] = pu.relerr(st["trace"]["masked_lat"], tr["masked_lat"][:B])
+    res["prep_pose_lat"] = pu.relerr(st["trace"]["pose_lat"], tr["pose_lat"][:B])
+    ptr = {}
+    lat = eng.denoise(st, use_graph=use_graph, trace=None if use_graph else ptr)
+    if not use_graph:
+        for i, (a, b) in enumerate(zip(ptr["step_latents"], tr["step_latents"])):
+            res[f"latents_step{i + 1}"] = pu.relerr(a, b)
+    res["latents_final"] = pu.relerr(lat, tr["step_latents"][-1])
+    res["image"] = pu.relerr(eng.decode(lat), img_o)
+    return res
