@@ -268,3 +268,16 @@ def random_state_dict(shapes, seed, dtype, device, std=0.02):
             t = t + 1.0
         sd[name] = t.to(dtype).to(device)
     return sd
+
+
+def fill_random_(views, seed, std=0.02):
+    """In-place seeded init of an arena's parameter views ON THEIR DEVICE (bench / multi-GPU path: weights are generated
+    by rank 0 directly in HBM and broadcast; same distribution as random_state_dict, different byte stream)."""
+    import torch
+    dev = next(iter(views.values())).device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, v in views.items():
+        v.normal_(0.0, std, generator=g)
+        if name.endswith(".weight") and v.dim() == 1:
+            v.add_(1.0)
+    return views

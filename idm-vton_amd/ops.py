@@ -23,6 +23,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch instrumentation (bench.py roofline leg): when PROFILE is a list, every C-ABI launch is bracketed
+# by HIP events on the launch stream and appended as (kernel family, start, end, flops, algorithmic bytes).
+PROFILE = None
+
+
+def _call(fn_name, args, flops=0.0, bytes_=0.0):
+    if PROFILE is None:
+        ffi.call(fn_name, args, _stream())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ffi.call(fn_name, args, _stream())
+    e1.record()
+    PROFILE.append((fn_name, e0, e1, flops, bytes_))
+
+
 def _dev(t):
     if not t.is_cuda:
         raise RuntimeError("idm_vton_amd ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
@@ -70,7 +86,7 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else ffi.EPI_NONE)
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.tile_hint = tile_hint
-    ffi.call("idmvton_gemm_conv", a, _stream())
+    _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot)
     return out
 
 
@@ -101,7 +117,10 @@ def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, 
         a.ldk[i], a.ldvt[i] = s["ldk"], s["ldvt"]
         a.nk[i], a.k_rows[i], a.seg_b0[i] = s["nk"], s.get("k_rows", 0), s.get("b0", 0)
     a.ip_scale = ip_scale
-    ffi.call("idmvton_attn_fwd", a, _stream())
+    fl = 0.0
+    for s in segs:
+        fl += 4.0 * (a.B - s.get("b0", 0)) * heads * a.Nq * s["nk"] * 64
+    _call("idmvton_attn_fwd", a, flops=fl, bytes_=2.0 * a.B * a.Nq * heads * 64 * q.element_size())
     return out
 
 
@@ -116,7 +135,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, out2=None):
     a.gamma, a.beta, a.eps = _ptr(gamma), _ptr(beta), eps
     a.y, a.ldy = _ptr(out), out.stride(0)
     a.y2, a.ldy2 = _ptr(out2), (out2.stride(0) if out2 is not None else 0)
-    ffi.call("idmvton_layernorm", a, _stream())
+    _call("idmvton_layernorm", a, bytes_=(2.0 + (out2 is not None)) * rows * Cc * x.element_size())
     return out
 
 
@@ -131,7 +150,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu, stats, x2=None, out=None):
     a.x, a.C1, a.x2 = _ptr(x), C1, _ptr(x2)
     a.gamma, a.beta, a.eps, a.silu = _ptr(gamma), _ptr(beta), eps, int(bool(silu))
     a.y, a.stats = _ptr(out), _ptr(stats)
-    ffi.call("idmvton_groupnorm", a, _stream())
+    _call("idmvton_groupnorm", a, bytes_=3.0 * B * HW * Cc * x.element_size())
     return out
 
 
@@ -140,7 +159,7 @@ def pack_input(latents, cond, out):
     B, hw = latents.shape[0], latents.shape[2] * latents.shape[3] if latents.dim() == 4 else latents.shape[2]
     a.dtype, a.B, a.hw, a.cpad = _dt(out), B, hw, out.shape[-1]
     a.latents, a.cond, a.out = _ptr(latents), _ptr(cond), _ptr(out)
-    ffi.call("idmvton_pack_input", a, _stream())
+    _call("idmvton_pack_input", a)
     return out
 
 
@@ -150,7 +169,7 @@ def cfg_step(eps_nhwc, latents, noise, coef):
     hw = latents.numel() // (B * 4)
     a.dtype, a.B, a.hw, a.ldc = _dt(eps_nhwc), B, hw, eps_nhwc.shape[-1]
     a.eps_nhwc, a.latents, a.noise, a.coef = _ptr(eps_nhwc), _ptr(latents), _ptr(noise), _ptr(coef)
-    ffi.call("idmvton_cfg_step", a, _stream())
+    _call("idmvton_cfg_step", a)
     return latents
 
 
@@ -163,7 +182,7 @@ def to_nhwc(src_nchw_f32, dtype, cpad=None, scale=1.0, shift=0.0, out=None):
     a = ffi.LayoutArgs()
     a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = _dt(out), B, Cc, HW, cpad, 1
     a.src, a.dst, a.scale, a.shift = _ptr(src_nchw_f32), _ptr(out), scale, shift
-    ffi.call("idmvton_layout", a, _stream())
+    _call("idmvton_layout", a)
     return out
 
 
@@ -174,7 +193,7 @@ def to_nchw(src_nhwc, Cc, shape_hw, scale=1.0, shift=0.0, out=None):
     a = ffi.LayoutArgs()
     a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = _dt(src_nhwc), B, Cc, HW, cpad, 0
     a.src, a.dst, a.scale, a.shift = _ptr(src_nhwc), _ptr(out), scale, shift
-    ffi.call("idmvton_layout", a, _stream())
+    _call("idmvton_layout", a)
     return out
 
 
@@ -185,7 +204,7 @@ def vae_sample(moments_nhwc, noise, scale, out=None):
     a = ffi.VaeSampleArgs()
     a.dtype, a.B, a.hw, a.ldm = _dt(moments_nhwc), B, hw, ldm
     a.moments, a.noise, a.z, a.scale = _ptr(moments_nhwc), _ptr(noise), _ptr(out), scale
-    ffi.call("idmvton_vae_sample", a, _stream())
+    _call("idmvton_vae_sample", a)
     return out
 
 
@@ -194,7 +213,7 @@ def softmax_rows(x, scale):
     a = ffi.SoftmaxArgs()
     a.dtype, a.rows, a.n, a.ld = _dt(x), x.shape[0], x.shape[1], x.stride(0)
     a.x, a.scale = _ptr(x), scale
-    ffi.call("idmvton_softmax_rows", a, _stream())
+    _call("idmvton_softmax_rows", a)
     return x
 
 

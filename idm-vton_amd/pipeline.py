@@ -12,10 +12,21 @@ from . import ops
 from .scheduler import StepScheduler
 
 
+def _copy_state(dst, src):
+    """Copy every tensor the captured step reads (latents, conditioning, K/V^T caches) into the graph's buffers."""
+    for k in ("latents", "cond", "cloth"):
+        dst[k].copy_(src[k])
+    for ck in ("ctx_t", "ctx_g"):
+        for p, ent in src[ck]["kv"].items():
+            for name, t in ent.items():
+                dst[ck]["kv"][p][name].copy_(t)
+
+
 class TryonEngine:
     def __init__(self, unet, unet_encoder, vae, resampler=None, dtype=torch.bfloat16, device="cuda"):
         self.unet, self.unet_encoder, self.vae, self.resampler = unet, unet_encoder, vae, resampler
         self.dtype, self.device = dtype, torch.device(device)
+        self._graphs = {}
 
     # -------------------------------------------------------------------------------------------- preparation
     @torch.no_grad()
@@ -82,26 +93,31 @@ class TryonEngine:
                 if trace is not None:
                     trace.setdefault("step_latents", []).append(st["latents"].clone())
             return st["latents"]
-        # ---- hipGraph: capture one step on static buffers, replay n times ----
-        tt, tg, cf = st["temb_t"][0].clone(), st["temb_g"][0].clone(), st["coef"][0].clone()
-        nz = st["steps_noise"][0].clone() if st["steps_noise"] is not None else None
-        saved = st["latents"].clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._step(st, tt, tg, cf, nz)                                                 # warm-up (allocator, lazy init)
-        torch.cuda.current_stream().wait_stream(side)
-        st["latents"].copy_(saved)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._step(st, tt, tg, cf, nz)
-        st["graph"] = graph
+        # ---- hipGraph: one step captured ONCE per shape on persistent buffers, replayed n times per call ----
+        key = (st["B"], st["h"], st["w"], n, st["steps_noise"] is not None)
+        if key not in self._graphs:
+            tt, tg, cf = st["temb_t"][0].clone(), st["temb_g"][0].clone(), st["coef"][0].clone()
+            nz = st["steps_noise"][0].clone() if st["steps_noise"] is not None else None
+            saved = st["latents"].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._step(st, tt, tg, cf, nz)                                             # warm-up (allocator, lazy init)
+            torch.cuda.current_stream().wait_stream(side)
+            st["latents"].copy_(saved)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step(st, tt, tg, cf, nz)
+            self._graphs[key] = (graph, st, tt, tg, cf, nz)
+        graph, sst, tt, tg, cf, nz = self._graphs[key]
+        if sst is not st:
+            _copy_state(sst, st)                                                           # new call -> persistent buffers
         for i in range(n):
             tt.copy_(st["temb_t"][i]); tg.copy_(st["temb_g"][i]); cf.copy_(st["coef"][i])
             if nz is not None:
                 nz.copy_(st["steps_noise"][i])
             graph.replay()
-        return st["latents"]
+        return sst["latents"]
 
     @torch.no_grad()
     def decode(self, latents):
