@@ -13,8 +13,9 @@ class StepScheduler:
         if kind not in ("ddpm", "ddim"):
             raise ValueError(f"unknown scheduler kind {kind!r}")
         self.kind, self.T, self.steps_offset = kind, num_train_timesteps, steps_offset
-        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float32) ** 2
-        self.alphas_cumprod = np.cumprod((1.0 - betas).astype(np.float32)).astype(np.float64)
+        import torch                      # same float32 linspace / cumprod ops as diffusers' DDPMScheduler.__init__
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double().numpy()
         self.init_noise_sigma = 1.0
         self.order = 1
 
