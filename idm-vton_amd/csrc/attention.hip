@@ -11,12 +11,15 @@
 // Key segments: SELF mode walks up to two segments under one softmax (own tokens, garment tokens); a segment that is
 // absent for this batch element (CFG-unconditional half: all-zero garment features) contributes nk keys with logit 0 and
 // value 0 in closed form (m0 = 0, l0 = nk).  CROSS mode keeps the two segments as separate softmaxes and sums the outputs.
-// Pipeline: 2 LDS buffers (16 KiB each), one barrier per 64-key tile: wait(t) -> barrier -> DMA(t+1) -> MFMA/softmax(t).
+// Pipeline: ST LDS stages of 16 KiB, one barrier per 64-key tile.  ST == 2: wait(t, vmcnt 0) -> __syncthreads -> DMA(t+1) ->
+// MFMA/softmax(t).  ST >= 3: ring, the DMA runs ST-1 tiles ahead and stays in flight across the raw s_barrier (counted
+// vmcnt: only tile t must have landed), see gemm_conv.hip.  The O / l rescale is skipped (wave-uniform branch) when no
+// lane's running max grew in this tile: alpha would be exactly 1, so the result is unchanged.
 #include "common.cuh"
 
 struct AttnParams {
     int B, heads, Nq;
-    const void* q; int ldq;
+    const void* q; int ldq; uint32_t qbytes;
     void* out; int ldo;
     int nseg;
     const void* k[2]; int ldk[2]; uint32_t kbytes[2];
@@ -28,13 +31,17 @@ struct AttnParams {
 
 #define NEG_BIG (-1.0e30f)
 
-template <typename T, int MODE, int NWAVES>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int MODE, int NWAVES, int ST>
 __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int QB = 32 * NWAVES;
     constexpr int IPW = 16 / NWAVES;                    // DMA instructions per wave per KV tile (8 K + 8 V^T in total)
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];   // [buf][K 8 KiB | V^T 8 KiB]
+    // [stage][K 8 KiB | V^T 8 KiB]; ring kernels add a per-wave 4 KiB Q tile (Q also arrives by LDS-DMA there: a plain
+    // global load of Q before the loop makes hipcc re-wait for it -- vmcnt(0) -- inside every iteration, draining the ring)
+    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + (ST > 2 ? NWAVES * 4096 : 0)];
 
     const int lane = threadIdx.x & 63;
     const int wave = uniform(threadIdx.x >> 6);
@@ -47,10 +54,24 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     // ---- Q fragments (MFMA B operand): column q = l31, k = d in [16s + 8u, +8) ----
     const int q_row = qb * QB + wave * 32 + l31;
     const int q_ld = q_row < p.Nq ? q_row : p.Nq - 1;
-    const T* qp = (const T*)p.q + ((size_t)b * p.Nq + q_ld) * p.ldq + h * 64 + 8 * u;
     v8 qf[4];
+    if constexpr (ST == 2) {
+        const T* qp = (const T*)p.q + ((size_t)b * p.Nq + q_ld) * p.ldq + h * 64 + 8 * u;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(qp + 16 * s);
+        for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(qp + 16 * s);
+    } else {
+        // Q tile of this wave: 32 rows x 128 B -> LDS (4 DMA instructions, same swizzle as K); read back after the first wait
+        const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(p.q, p.qbytes);
+        char* dq = smem + ST * 16384 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            int row = qb * QB + wave * 32 + R;
+            row = row < p.Nq ? row : p.Nq - 1;
+            dma16(rs_q, dq + i * 1024, (uint32_t)((((size_t)b * p.Nq + row) * p.ldq + h * 64 + c * 8) * 2));
+        }
+    }
 
     // ---- which segments exist for this batch element (block-uniform) ----
     const bool pres0 = p.nseg > 0 && b >= p.seg_b0[0];
@@ -109,12 +130,32 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
         if (nz > 0) { m_run = 0.f; l_run = u == 0 ? (float)nz : 0.f; }
     }
 
-    if (nt > 0) issue(0, 0);
+    if constexpr (ST == 2) { if (nt > 0) issue(0, 0); }
+    else {
+#pragma unroll
+        for (int s = 0; s < ST - 1; ++s)
+            if (s < nt) issue(s, s);
+        // Q (the oldest DMAs, issued by this wave for itself) has landed once at most the prologue tiles are outstanding
+        if (nt >= ST - 1) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();
+        const char* dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(dq + (((2 * s + u) ^ ((l31 >> 1) & 7)) << 4));
+    }
+    int cbuf = 0, ibuf = ST - 1;
     for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
-        const char* buf = smem + (t & 1) * 16384;
+        if constexpr (ST == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        } else {
+            if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * IPW>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + ST - 1 < nt) issue(t + ST - 1, ibuf);
+        }
+        const char* buf = smem + cbuf * 16384;
+        cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
+        ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
         const int sg = t < nt0 ? 0 : 1;
         const int kt = sg ? t - nt0 : t;
         const int valid = p.nk[sg] - kt * 64;            // keys of this tile that exist (>= 64: all)
@@ -148,8 +189,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx * cs);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        const bool grew = m_new > m_run;
         float psum = 0.f;
         v8 pf[4];
 #pragma unroll
@@ -160,11 +200,16 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
                 psum += pv;
                 pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
             }
-        l_run = l_run * alpha + psum;
+        if (ST == 2 || __any(grew)) {                    // no lane's max moved: alpha == 1 exactly, skip the O rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
+        m_run = m_new;
+        l_run += psum;
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -209,18 +254,23 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 }
 
 template <typename T, int MODE>
-static int launch_attn(AttnParams& p, hipStream_t st) {
+static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
+    // tune = (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring.
     const long rows = (long)p.B * p.heads * p.Nq;
-    int nw = 4;
+    int nw = 4, stg = 2;
     if (rows / 128 < 512) nw = 2;
     if (rows / 128 >= 2048) nw = 8;
+    if (tune) { nw = tune & 0xff; stg = (tune >> 8) & 0xff; }
     const int qbs = 32 * nw;
     p.nqb = (p.Nq + qbs - 1) / qbs;
     const dim3 grid(p.nqb * p.heads * p.B), block(nw * 64);
-    if (nw == 2) hipLaunchKernelGGL((attn_kernel<T, MODE, 2>), grid, block, 0, st, p);
-    else if (nw == 4) hipLaunchKernelGGL((attn_kernel<T, MODE, 4>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_kernel<T, MODE, 8>), grid, block, 0, st, p);
+#define ATTN_CASE(NW_, ST_) if (nw == NW_ && stg == ST_) { hipLaunchKernelGGL((attn_kernel<T, MODE, NW_, ST_>), grid, block, 0, st, p); } else
+    ATTN_CASE(2, 2) ATTN_CASE(4, 2) ATTN_CASE(8, 2)
+    ATTN_CASE(2, 3) ATTN_CASE(4, 3) ATTN_CASE(8, 3)
+    ATTN_CASE(2, 4) ATTN_CASE(4, 4) ATTN_CASE(8, 4)
+    return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: unsupported tune (waves=%d stages=%d)", nw, stg);
+#undef ATTN_CASE
     CHECK_LAUNCH("attn_fwd");
     return IDMVTON_OK;
 }
@@ -239,6 +289,9 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
     AttnParams p;
     p.B = a->B; p.heads = a->heads; p.Nq = a->Nq; p.q = a->q; p.ldq = a->ldq; p.out = a->out; p.ldo = a->ldo;
     p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0;
+    const uint64_t qb = ((uint64_t)a->B * a->Nq - 1) * a->ldq * 2 + (uint64_t)a->heads * 128;
+    CHECK_ARG(qb < 0x80000000ull, IDMVTON_E_SHAPE, "attn_fwd: Q >= 2 GiB");
+    p.qbytes = (uint32_t)qb;
     for (int s = 0; s < 2; ++s) {
         const int ss = s < a->nseg ? s : 0;
         CHECK_ARG(a->k[ss] && a->vt[ss] && a->nk[ss] > 0 && a->seg_b0[ss] >= 0 && a->seg_b0[ss] <= a->B,
@@ -257,6 +310,6 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == IDMVTON_BF16)
-        return a->mode == IDMVTON_ATTN_SELF ? launch_attn<bf16_t, IDMVTON_ATTN_SELF>(p, st) : launch_attn<bf16_t, IDMVTON_ATTN_CROSS>(p, st);
-    return a->mode == IDMVTON_ATTN_SELF ? launch_attn<f16_t, IDMVTON_ATTN_SELF>(p, st) : launch_attn<f16_t, IDMVTON_ATTN_CROSS>(p, st);
+        return a->mode == IDMVTON_ATTN_SELF ? launch_attn<bf16_t, IDMVTON_ATTN_SELF>(p, a->tune, st) : launch_attn<bf16_t, IDMVTON_ATTN_CROSS>(p, a->tune, st);
+    return a->mode == IDMVTON_ATTN_SELF ? launch_attn<f16_t, IDMVTON_ATTN_SELF>(p, a->tune, st) : launch_attn<f16_t, IDMVTON_ATTN_CROSS>(p, a->tune, st);
 }

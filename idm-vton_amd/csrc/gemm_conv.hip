@@ -12,7 +12,15 @@
 // the XOR is applied to the per-lane SOURCE address (permutation inside one 128-byte line: still one cache line per
 // 8 lanes) and again on the ds_read_b128 fragment reads, which makes every 16-lane read group hit 16 distinct 16-byte
 // bank slots (conflict-free).
-// Pipeline: 2 LDS buffers, one barrier per 64-deep K tile: wait(tile t) -> barrier -> issue DMA(tile t+1) -> MFMA(tile t).
+// Pipeline, two forms (template parameter ST = LDS stages):
+//   ST == 2 : wait(tile t, vmcnt 0) -> __syncthreads -> issue DMA(tile t+1) -> MFMA(tile t)      (latency hidden by 2-3 blocks/CU)
+//   ST >= 3 : ring of ST buffers, DMA runs ST-1 tiles ahead and stays in flight ACROSS the barrier: counted
+//             `s_waitcnt vmcnt((ST-2)*loads_per_tile)` (only tile t must have landed) -> raw s_barrier -> issue
+//             DMA(tile t+ST-1) into the buffer tile t-1 was read from (every wave is past compute(t-1) once it has passed
+//             this barrier) -> MFMA(tile t).  Used with 8-wave 256x128 tiles (144 KiB LDS, 48 B/clk/CU of operand traffic
+//             instead of 64 for 128x128) and with small tiles where 1-2 blocks per CU cannot hide the HBM/L2 latency.
+// LIN = plain Linear (one K segment, no spatial gather): the activation operand's DMA offsets are precomputed like the
+// weight's, so issuing a tile costs one add per DMA instead of the ~12 VALU of the conv gather.
 #include "common.cuh"
 
 struct GemmParams {
@@ -27,20 +35,26 @@ struct GemmParams {
     int tiles_m, tiles_n;
 };
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
-template <typename T, int BN, int BM, bool TR>
+// Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool LIN, bool PF, bool TR>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
-    constexpr int NI = BN / 64, MI = BM / 64;          // 32x32 MFMA tiles per wave along n / m
-    constexpr int WBYTES = BN * 128, XBYTES = BM * 128; // one LDS buffer of each operand
-    constexpr int WI = BN / 32, XI = BM / 32;           // DMA instructions per wave per tile
+    constexpr int NW = WN * WM;
+    constexpr int SN = BN / WN, SM = BM / WM;           // wave sub-tile
+    constexpr int NI = SN / 32, MI = SM / 32;           // 32x32 MFMA tiles per wave along n / m
+    constexpr int WBYTES = BN * 128, XBYTES = BM * 128; // one LDS stage of each operand
+    constexpr int WI = BN / (8 * NW), XI = BM / (8 * NW); // DMA instructions per wave per tile (8 rows each)
+    static_assert(WI >= 1 && XI >= 1 && WI * 8 * NW == BN && XI * 8 * NW == BM, "tile / wave-count mismatch");
     char* sW = smem;
-    char* sX = smem + 2 * WBYTES;
+    char* sX = smem + ST * WBYTES;
 
     const int lane = threadIdx.x & 63;
     const int wave = uniform(threadIdx.x >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = wave / WM, wm = wave % WM;
     const int u = lane >> 5, l31 = lane & 31;
 
     // ---- loader state: this lane's rows / swizzled chunk for each DMA instruction it issues ----
@@ -53,13 +67,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         w_off[i] = ((uint32_t)(n0 + R) * (uint32_t)p.Ktot + c * 8) * 2u;   // rows >= N fall beyond num_records -> 0
     }
     int x_pix[XI], x_oy[XI], x_ox[XI], x_c8[XI];
+    uint32_t x_off[XI];                                  // LIN only
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int R = (wave * XI + i) * 8 + lrow;
         const int m = m0 + R;
         x_c8[i] = (lslot ^ ((R >> 1) & 7)) * 8;
-        if (m < p.M) {
+        if constexpr (LIN) {
+            x_off[i] = m < p.M ? ((uint32_t)m * (uint32_t)p.seg[0].pitch + p.seg[0].coff + x_c8[i]) * 2u : OOB_SENTINEL;
+        } else if (m < p.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             x_pix[i] = b * p.Hi * p.Wi; x_oy[i] = oy * p.stride; x_ox[i] = ox * p.stride;
@@ -68,34 +85,41 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     }
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t rs_x0 = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
     const int hin = p.ups ? 2 * p.Hi : p.Hi, win = p.ups ? 2 * p.Wi : p.Wi;
 
     int si = 0, kseg = 0;                                // K-segment cursor of the NEXT tile to issue
     auto issue = [&](int t, int buf) {
-        const idmvton_seg sg = p.seg[si];
-        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(sg.ptr, sg.bytes);
         char* dW = sW + buf * WBYTES + wave * (WI * 1024);
         char* dX = sX + buf * XBYTES + wave * (XI * 1024);
 #pragma unroll
         for (int i = 0; i < WI; ++i) dma16(rs_w, dW + i * 1024, w_off[i] + (uint32_t)t * 128u);
+        if constexpr (LIN) {
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            int iy = x_oy[i] + sg.dy, ix = x_ox[i] + sg.dx;
-            const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
-            if (p.ups) { iy >>= 1; ix >>= 1; }
-            const uint32_t off = ((uint32_t)(x_pix[i] + iy * p.Wi + ix) * (uint32_t)sg.pitch + sg.coff + kseg + x_c8[i]) * 2u;
-            dma16(rs_x, dX + i * 1024, ok ? off : OOB_SENTINEL);
+            for (int i = 0; i < XI; ++i)                  // OOB_SENTINEL + t*128 stays >= 2 GiB > num_records
+                dma16(rs_x0, dX + i * 1024, x_off[i] + (uint32_t)t * 128u);
+        } else {
+            const idmvton_seg sg = p.seg[si];
+            const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(sg.ptr, sg.bytes);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                int iy = x_oy[i] + sg.dy, ix = x_ox[i] + sg.dx;
+                const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                const uint32_t off = ((uint32_t)(x_pix[i] + iy * p.Wi + ix) * (uint32_t)sg.pitch + sg.coff + kseg + x_c8[i]) * 2u;
+                dma16(rs_x, dX + i * 1024, ok ? off : OOB_SENTINEL);
+            }
+            kseg += 64;
+            if (kseg >= sg.len) { kseg = 0; ++si; }
         }
-        kseg += 64;
-        if (kseg >= sg.len) { kseg = 0; ++si; }
     };
 
     // ---- fragment read addresses (row*128 and the row's swizzle key) ----
     int a_row[NI], a_swz[NI], b_row[MI], b_swz[MI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { const int r = wn * (BN / 2) + ni * 32 + l31; a_row[ni] = r * 128; a_swz[ni] = (r >> 1) & 7; }
+    for (int ni = 0; ni < NI; ++ni) { const int r = wn * SN + ni * 32 + l31; a_row[ni] = r * 128; a_swz[ni] = (r >> 1) & 7; }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) { const int r = wm * (BM / 2) + mi * 32 + l31; b_row[mi] = r * 128; b_swz[mi] = (r >> 1) & 7; }
+    for (int mi = 0; mi < MI; ++mi) { const int r = wm * SM + mi * 32 + l31; b_row[mi] = r * 128; b_swz[mi] = (r >> 1) & 7; }
 
     f32x16 acc[NI][MI];
 #pragma unroll
@@ -105,26 +129,78 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
+    auto frag_a = [&](const char* bW, int s, int ni) { return *(const v8*)(bW + a_row[ni] + (((2 * s + u) ^ a_swz[ni]) << 4)); };
+    auto frag_b = [&](const char* bX, int s, int mi) { return *(const v8*)(bX + b_row[mi] + (((2 * s + u) ^ b_swz[mi]) << 4)); };
+    auto compute = [&](int buf) {
+        const char* bW = sW + buf * WBYTES;
+        const char* bX = sX + buf * XBYTES;
+        if constexpr (!PF) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                v8 a[NI], b[MI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) a[ni] = frag_a(bW, s, ni);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) b[mi] = frag_b(bX, s, mi);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = TR ? VT<T>::mfma(b[mi], a[ni], acc[ni][mi]) : VT<T>::mfma(a[ni], b[mi], acc[ni][mi]);
+            }
+        } else {
+            // one wave per SIMD (no partner wave to cover the LDS latency): fragments double-buffered in registers, the
+            // ds_reads of k-step s+1 are pinned ahead of the MFMAs of step s
+            v8 a[2][NI], b[2][MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) a[0][ni] = frag_a(bW, 0, ni);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) b[0][mi] = frag_b(bX, 0, mi);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) a[(s + 1) & 1][ni] = frag_a(bW, s + 1, ni);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) b[(s + 1) & 1][mi] = frag_b(bX, s + 1, mi);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = TR ? VT<T>::mfma(b[s & 1][mi], a[s & 1][ni], acc[ni][mi])
+                                         : VT<T>::mfma(a[s & 1][ni], b[s & 1][mi], acc[ni][mi]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
     const int nt = p.Ktot >> 6;
-    issue(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
-        const char* bW = sW + (t & 1) * WBYTES;
-        const char* bX = sX + (t & 1) * XBYTES;
+    if constexpr (ST == 2) {
+        issue(0, 0);
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+            compute(t & 1);
+        }
+    } else {
+        constexpr int LPT = WI + XI;                     // DMA instructions per wave per tile
+        static_assert((ST - 2) * LPT < 64, "vmcnt immediate is 6 bits");
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            v8 a[NI], b[MI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) a[ni] = *(const v8*)(bW + a_row[ni] + (((2 * s + u) ^ a_swz[ni]) << 4));
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) b[mi] = *(const v8*)(bX + b_row[mi] + (((2 * s + u) ^ b_swz[mi]) << 4));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = TR ? VT<T>::mfma(b[mi], a[ni], acc[ni][mi]) : VT<T>::mfma(a[ni], b[mi], acc[ni][mi]);
+        for (int s = 0; s < ST - 1; ++s)
+            if (s < nt) issue(s, s);
+        int cbuf = 0, ibuf = ST - 1;                     // buffer computed this iteration / buffer refilled this iteration
+        for (int t = 0; t < nt; ++t) {
+            // tiles t .. t+ST-2 are outstanding (fewer at the tail); only tile t has to have landed
+            if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                // every wave's share of tile t landed; all are done with tile t-1
+            asm volatile("" ::: "memory");
+            if (t + ST - 1 < nt) issue(t + ST - 1, ibuf);
+            compute(cbuf);
+            cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
+            ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
         }
     }
 
@@ -136,14 +212,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         const int Cv = p.N - p.vt_n0;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * (BN / 2) + ni * 32 + l31;
+            const int n = n0 + wn * SN + ni * 32 + l31;
             if (n >= p.N) continue;
             const float bv = bias ? (float)bias[n] : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m = m0 + wm * (BM / 2) + mi * 32 + 8 * g + 4 * u;
+                    const int m = m0 + wm * SM + mi * 32 + 8 * g + 4 * u;
                     if (m >= p.M) continue;
                     const int b = m / p.vt_tokens, tok = m - b * p.vt_tokens;
                     v4 o;
@@ -159,16 +235,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     const T* rowbias = (const T*)p.rowbias;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * (BM / 2) + mi * 32 + l31;
+        const int m = m0 + wm * SM + mi * 32 + l31;
         if (m >= p.M) continue;
         const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
         if (p.mode == IDMVTON_EPI_GEGLU) {
             if constexpr (NI == 2) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int nh = n0 + wn * 64 + 8 * g + 4 * u;          // h rows; gate rows are nh + 32
+                    const int nh = n0 + wn * SN + 8 * g + 4 * u;          // h rows; gate rows are nh + 32
                     if (nh + 32 >= p.N) continue;
-                    const int jo = ((n0 + wn * 64) >> 1) + 8 * g + 4 * u;
+                    const int jo = ((n0 + wn * SN) >> 1) + 8 * g + 4 * u;
                     v4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -185,7 +261,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * (BN / 2) + ni * 32 + 8 * g + 4 * u;
+                const int n = n0 + wn * SN + ni * 32 + 8 * g + 4 * u;
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -217,26 +293,57 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     }
 }
 
-template <typename T, int BN, int BM>
-__global__ __launch_bounds__(256, (BN + BM >= 256 ? 2 : 3)) void gemm_conv_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * (BN + BM) * 128];
+// Tile configurations.  id = the `variant` field of tile_hint (bits 28..31); BN/BM in bits 16..27 / 0..15.
+//   v0 (ST=2, 4 waves): 128x128, 128x64, 64x64           -- 2-3 blocks per CU hide the load latency
+//   v1 (ring)         : 128x256 8 waves ST=3 (144 KiB, 1 block/CU), 128x128 4 waves ST=3 (96 KiB),
+//                       128x64 4 waves ST=3 (72 KiB, 2 blocks/CU), 64x64 4 waves ST=4 (64 KiB, 2 blocks/CU)
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool LIN, int OCC>
+__global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    int tm, tn;
+    if constexpr (ST == 2) { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
+    else {
+        // grouped raster: the ~32-64 tiles an XCD runs concurrently form a ~1024 x 1024 output patch (GM m-tiles tall), so
+        // the operand rows they share stay in that XCD's 4 MiB L2 instead of being re-fetched per tile row
+        constexpr int GM = 1024 / BM;
+        const int width = GM * p.tiles_n;
+        const int grp = wg / width, rem = wg - grp * width;
+        const int first = grp * GM;
+        const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
+        tn = rem / gsz; tm = first + (rem - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, true>(p, smem, m0, n0);   // block-uniform
-    else gemm_body<T, BN, BM, false>(p, smem, m0, n0);
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, LIN, OCC == 1, true>(p, smem, m0, n0);   // block-uniform
+    else gemm_body<T, BN, BM, WN, WM, ST, LIN, OCC == 1, false>(p, smem, m0, n0);
+}
+
+template <typename T, int BN, int BM, int WN, int WM, int ST, int OCC>
+static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
+    const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
+    if constexpr (ST > 2) {                              // the ST == 2 kernels keep the one general loader
+        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, OCC>), grid, block, 0, st, p); return; }
+    }
+    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, false, OCC>), grid, block, 0, st, p);
 }
 
 template <typename T>
-static int launch_gemm(const GemmParams& p0, int bn, int bm, hipStream_t st) {
+static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool lin, hipStream_t st) {
     GemmParams p = p0;
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tiles_m = (p.M + bm - 1) / bm;
-    const dim3 grid(p.tiles_n * p.tiles_m), block(256);
-    if (bn == 128 && bm == 128) hipLaunchKernelGGL((gemm_conv_kernel<T, 128, 128>), grid, block, 0, st, p);
-    else if (bn == 128 && bm == 64) hipLaunchKernelGGL((gemm_conv_kernel<T, 128, 64>), grid, block, 0, st, p);
-    else if (bn == 64 && bm == 64) hipLaunchKernelGGL((gemm_conv_kernel<T, 64, 64>), grid, block, 0, st, p);
-    else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported tile %dx%d", bn, bm);
+    if (variant == 0) {
+        if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 2, 2>(p, lin, st);
+        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 2, 3>(p, lin, st);
+        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 2, 3>(p, lin, st);
+        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v0 tile %dx%d", bn, bm);
+    } else if (variant == 1) {
+        if (bn == 128 && bm == 256) launch_cfg<T, 128, 256, 2, 4, 3, 2>(p, lin, st);
+        else if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 3, 1>(p, lin, st);
+        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, 2>(p, lin, st);
+        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, 2>(p, lin, st);
+        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v1 tile %dx%d", bn, bm);
+    } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;
 }
@@ -286,9 +393,10 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4;
     p.tiles_m = p.tiles_n = 0;
 
-    // Tile choice: largest tile that still gives >= 2 workgroups per CU (256 CUs); GEGLU needs 64-row wave tiles (BN=128).
-    int bn = 128, bm = 128;
-    if (a->tile_hint) { bn = a->tile_hint >> 16; bm = a->tile_hint & 0xffff; }
+    // Tile choice: tile_hint (variant<<28 | BN<<16 | BM) from the caller's tuning table, else the largest v0 tile that
+    // still gives >= 2 workgroups per CU (256 CUs); GEGLU needs 64-row wave tiles (BN=128).
+    int variant = 0, bn = 128, bm = 128;
+    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0xffff; }
     else {
         auto tiles = [&](int n_, int m_) { return (long)((a->N + n_ - 1) / n_) * ((a->M + m_ - 1) / m_); };
         if (tiles(128, 128) >= 512) { bn = 128; bm = 128; }
@@ -297,6 +405,9 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     }
     if (geglu) CHECK_ARG(bn == 128, IDMVTON_E_ARG, "gemm_conv: GEGLU needs BN=128");
     if (a->vt) CHECK_ARG(a->vt_n0 % bn == 0, IDMVTON_E_ARG, "gemm_conv: vt_n0 %% BN != 0");
+    const idmvton_seg& s0 = a->seg[0];
+    const bool lin = a->nseg == 1 && a->Ho == 1 && a->Hi == 1 && a->Wo == a->M && a->Wi == a->M && a->stride == 1 &&
+                     !a->ups && s0.dy == 0 && s0.dx == 0 && (uint64_t)a->M * s0.pitch * 2 < 0x80000000ull;
     hipStream_t st = (hipStream_t)stream;
-    return a->dtype == IDMVTON_BF16 ? launch_gemm<bf16_t>(p, bn, bm, st) : launch_gemm<f16_t>(p, bn, bm, st);
+    return a->dtype == IDMVTON_BF16 ? launch_gemm<bf16_t>(p, variant, bn, bm, lin, st) : launch_gemm<f16_t>(p, variant, bn, bm, lin, st);
 }

@@ -32,7 +32,7 @@ class GemmConvArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("mode", i32), ("B", i32), ("heads", i32), ("Nq", i32), ("q", vp), ("ldq", i32),
                 ("out", vp), ("ldo", i32), ("nseg", i32), ("k", vp * 2), ("ldk", i32 * 2), ("vt", vp * 2),
-                ("ldvt", i32 * 2), ("nk", i32 * 2), ("k_rows", i32 * 2), ("seg_b0", i32 * 2), ("ip_scale", f32)]
+                ("ldvt", i32 * 2), ("nk", i32 * 2), ("k_rows", i32 * 2), ("seg_b0", i32 * 2), ("ip_scale", f32), ("tune", i32)]
 
 
 class LayerNormArgs(C.Structure):

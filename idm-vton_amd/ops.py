@@ -69,7 +69,9 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     for i, s in enumerate(segs):
         t = _dev(s.t)
         g = a.seg[i]
-        g.ptr, g.bytes, g.pitch = t.data_ptr(), t.numel() * t.element_size(), t.shape[-1]
+        pitch = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+        extent = 1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride()))     # elements reachable from data_ptr
+        g.ptr, g.bytes, g.pitch = t.data_ptr(), extent * t.element_size(), pitch
         g.coff, g.len, g.dy, g.dx = s.coff, s.len, s.dy, s.dx
     Wo = M if Wo is None else Wo
     Wi = M if Wi is None else Wi
@@ -102,7 +104,7 @@ def conv_segs(x, k, pad, coff=0, length=None):
     return [SegSpec(x, coff, length, ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
 
 
-def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, Nq=None, ldq=None, ldo=None):
+def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, Nq=None, ldq=None, ldo=None, tune=0):
     """q/out: [B][Nq][>=heads*64] views; segs: list of dict(k=, vt=, nk=, ldk=, ldvt=, k_rows=, b0=)."""
     a = ffi.AttnArgs()
     a.dtype, a.mode = _dt(q), mode
@@ -117,6 +119,7 @@ def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, 
         a.ldk[i], a.ldvt[i] = s["ldk"], s["ldvt"]
         a.nk[i], a.k_rows[i], a.seg_b0[i] = s["nk"], s.get("k_rows", 0), s.get("b0", 0)
     a.ip_scale = ip_scale
+    a.tune = tune
     fl = 0.0
     for s in segs:
         fl += 4.0 * (a.B - s.get("b0", 0)) * heads * a.Nq * s["nk"] * 64

@@ -27,6 +27,7 @@ class TryonEngine:
         self.unet, self.unet_encoder, self.vae, self.resampler = unet, unet_encoder, vae, resampler
         self.dtype, self.device = dtype, torch.device(device)
         self._graphs = {}
+        self._side = None
 
     # -------------------------------------------------------------------------------------------- preparation
     @torch.no_grad()
@@ -76,6 +77,8 @@ class TryonEngine:
 
     # -------------------------------------------------------------------------------------------- one step
     def _step(self, st, temb_t, temb_g, coef, noise):
+        """Serial form of one loop iteration (tryon_pipeline.py:1765-1866) on the current stream: parity tests, traces and
+        the per-kernel roofline leg of bench.py use this; the throughput path is the two-stream form below."""
         B, h, w = st["B"], st["h"], st["w"]
         ops.pack_input(st["latents"], st["cond"], st["x_in"])                              # :1769,1777
         _, feats = self.unet_encoder.forward(st["cloth"], temb_g, st["ctx_g"], B, h, w)    # :1787
@@ -83,9 +86,115 @@ class TryonEngine:
         ops.cfg_step(eps, st["latents"], noise, coef)                                      # :1814-1823
         return eps
 
-    @torch.no_grad()
-    def denoise(self, st, use_graph=False, trace=None):
+    # GarmentNet's inputs (cloth latent, cloth text, timestep) do not depend on the latents, so GarmentNet for step i+1 --
+    # and the attn1 K / V^T projections of its 70 features with TryonNet's weights -- run on a second HIP stream while
+    # TryonNet runs step i.  Two feature sets alternate; there is no other coupling between the streams.
+    def _garment_side(self, st, temb_g, fset):
+        B, h, w = st["B"], st["h"], st["w"]
+        self.unet_encoder.forward(st["cloth"], temb_g, st["ctx_g"], B, h, w, feats_buf=fset["feats"])      # :1787
+        self.unet.project_garment_kv(fset["feats"], out=fset["kv"])
+
+    def _tryon_main(self, st, temb_t, coef, noise, fset):
+        B, h, w = st["B"], st["h"], st["w"]
+        ops.pack_input(st["latents"], st["cond"], st["x_in"])                              # :1769,1777
+        eps, _ = self.unet.forward(st["x_in"], temb_t, st["ctx_t"], 2 * B, h, w, garment_kv=fset["kv"])  # :1796-1808
+        ops.cfg_step(eps, st["latents"], noise, coef)                                      # :1814-1823
+        return eps
+
+    def _feature_sets(self, st, temb_g0):
+        """Two persistent {70 features, 70 (K, V^T)} sets; set 0 is filled for the first step on the current stream."""
+        B, h, w = st["B"], st["h"], st["w"]
+        _, feats = self.unet_encoder.forward(st["cloth"], temb_g0, st["ctx_g"], B, h, w)
+        kv = self.unet.project_garment_kv(feats)
+        s0 = dict(feats=feats, kv=kv)
+        s1 = dict(feats=[torch.empty_like(f) for f in feats], kv=[(torch.empty_like(k), torch.empty_like(v)) for k, v in kv])
+        return [s0, s1]
+
+    def _denoise_overlap_eager(self, st):
         n = len(st["timesteps"])
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        sets = self._feature_sets(st, st["temb_g"][0])
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        free = [torch.cuda.Event(), torch.cuda.Event()]
+        side.wait_stream(main)                                       # prepare()'s tensors and set 0 are complete
+        for i in range(n):
+            cur, nxt = i & 1, (i + 1) & 1
+            if i + 1 < n:
+                with torch.cuda.stream(side):
+                    if i >= 1:
+                        side.wait_event(free[nxt])                   # TryonNet step i-1 is done reading set nxt
+                    self._garment_side(st, st["temb_g"][i + 1], sets[nxt])
+                    ready[nxt].record(side)
+            if i >= 1:
+                main.wait_event(ready[cur])
+            nz = st["steps_noise"][i] if st["steps_noise"] is not None else None
+            self._tryon_main(st, st["temb_t"][i], st["coef"][i], nz, sets[cur])
+            free[cur].record(main)
+        main.wait_stream(side)
+        return st["latents"]
+
+    def _denoise_overlap_graph(self, st):
+        """hipGraph form of the two-stream loop: per parity one graph with two parallel branches {TryonNet step i on set p |
+        GarmentNet step i+1 into set p^1}, plus a TryonNet-only graph for the last step.  Consecutive graph launches are
+        ordered on the launching stream, which is exactly the dependency the two sets need."""
+        n = len(st["timesteps"])
+        has_noise = st["steps_noise"] is not None
+        key = (st["B"], st["h"], st["w"], has_noise, "overlap")
+        if key not in self._graphs:
+            tt, tg, cf = st["temb_t"][0].clone(), st["temb_g"][0].clone(), st["coef"][0].clone()
+            nz = st["steps_noise"][0].clone() if has_noise else None
+            saved = st["latents"].clone()
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):                            # warm-up off the default stream (allocator, lazy init)
+                sets = self._feature_sets(st, tg)
+                self._garment_side(st, tg, sets[1])
+                self._tryon_main(st, tt, cf, nz, sets[0])
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            st["latents"].copy_(saved)
+            side = torch.cuda.Stream()
+            pair, last = {}, {}
+            for par in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    cap = torch.cuda.current_stream()
+                    side.wait_stream(cap)                            # fork
+                    with torch.cuda.stream(side):
+                        self._garment_side(st, tg, sets[par ^ 1])
+                    self._tryon_main(st, tt, cf, nz, sets[par])
+                    cap.wait_stream(side)                            # join
+                pair[par] = g
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    self._tryon_main(st, tt, cf, nz, sets[par])
+                last[par] = g2
+            st["latents"].copy_(saved)
+            self._graphs[key] = dict(st=st, tt=tt, tg=tg, cf=cf, nz=nz, sets=sets, pair=pair, last=last)
+        G = self._graphs[key]
+        sst, tt, tg, cf, nz = G["st"], G["tt"], G["tg"], G["cf"], G["nz"]
+        if sst is not st:
+            _copy_state(sst, st)                                                           # new call -> persistent buffers
+        self._garment_side(sst, st["temb_g"][0].contiguous(), G["sets"][0])               # step 0's features (eager, once)
+        for i in range(n):
+            tt.copy_(st["temb_t"][i]); cf.copy_(st["coef"][i])
+            if nz is not None:
+                nz.copy_(st["steps_noise"][i])
+            if i + 1 < n:
+                tg.copy_(st["temb_g"][i + 1])
+                G["pair"][i & 1].replay()
+            else:
+                G["last"][i & 1].replay()
+        return sst["latents"]
+
+    @torch.no_grad()
+    def denoise(self, st, use_graph=False, trace=None, overlap=False):
+        n = len(st["timesteps"])
+        if overlap and trace is None:
+            return self._denoise_overlap_graph(st) if use_graph else self._denoise_overlap_eager(st)
         if not use_graph:
             for i in range(n):
                 nz = st["steps_noise"][i] if st["steps_noise"] is not None else None
@@ -125,7 +234,7 @@ class TryonEngine:
         return (img / 2 + 0.5).clamp(0, 1)                                                 # postprocess
 
     @torch.no_grad()
-    def __call__(self, *, return_latents=False, use_graph=False, **kw):
+    def __call__(self, *, return_latents=False, use_graph=False, overlap=False, **kw):
         st = self.prepare(**kw)
-        lat = self.denoise(st, use_graph=use_graph)
+        lat = self.denoise(st, use_graph=use_graph, overlap=overlap)
         return lat if return_latents else self.decode(lat)

@@ -111,6 +111,8 @@ class HipUNet:
                     prep_tf(f"up_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"])
             if blk["up"]:
                 self.res[f"up_blocks.{i}.upsamplers.0.conv"] = _Conv(sd, f"up_blocks.{i}.upsamplers.0.conv")
+        # transformer blocks in traversal order == GarmentNet feature order (unet_hacked_tryon.py:1254 running index)
+        self.block_order = [blk for tf in self.tf.values() for blk in tf["blocks"]]
         self.temb_w = torch.cat(temb_w).contiguous()          # one GEMM for every resnet's time_emb_proj
         self.temb_b = torch.cat(temb_b).contiguous()
         if self.tryon:
@@ -210,8 +212,9 @@ class HipUNet:
         dt, dev = self.dtype, self.device
         M = B * N
         feat = None
-        if not self.tryon:
-            feat = torch.empty(M, C, dtype=dt, device=dev)      # exported norm1 output (garmnet :321-322)
+        if not self.tryon:                                       # exported norm1 output (garmnet :321-322)
+            fb = garment.get("feats_buf") if garment else None
+            feat = fb[len(feats_out)].view(M, C) if fb is not None else torch.empty(M, C, dtype=dt, device=dev)
         n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
         if feat is not None:
             feats_out.append(feat.view(B, N, C))
@@ -222,12 +225,16 @@ class HipUNet:
         ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N)
         segs = [dict(k=qk[:, C:], vt=vt, nk=N, ldk=2 * C, ldvt=N)]
         if self.tryon:
-            g = garment["feats"][garment["idx"]]                # [Bg][N][C]
+            if garment.get("kv") is not None:                   # K / V^T of the garment tokens projected ahead of time
+                kg, vtg = garment["kv"][garment["idx"]]         # (project_garment_kv, on the GarmentNet stream)
+                Bg = vtg.shape[0]
+            else:
+                g = garment["feats"][garment["idx"]]            # [Bg][N][C]
+                Bg = g.shape[0]
+                kg = torch.empty(Bg * N, C, dtype=dt, device=dev)
+                vtg = torch.empty(Bg, C, N, dtype=dt, device=dev)
+                ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
             garment["idx"] += 1
-            Bg = g.shape[0]
-            kg = torch.empty(Bg * N, C, dtype=dt, device=dev)
-            vtg = torch.empty(Bg, C, N, dtype=dt, device=dev)
-            ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
             segs.append(dict(k=kg, vt=vtg, nk=N, ldk=C, ldvt=N, b0=B - Bg))
         att = torch.empty(M, C, dtype=dt, device=dev)
         ops.attention(qk, att, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C)
@@ -266,13 +273,30 @@ class HipUNet:
     def num_features(self):
         return sum(len(t["blocks"]) for t in self.tf.values())
 
+    def project_garment_kv(self, feats, out=None):
+        """TryonNet only: attn1.to_k / to_v of every block applied to the matching GarmentNet feature (the garment half of
+        the concatenated self-attention input, attentionhacked_tryon.py:334-342) -> [(K [Bg*N][C], V^T [Bg][C][N])] * 70.
+        It depends only on GarmentNet's output, so the engine runs it on the GarmentNet stream, one step ahead of TryonNet."""
+        assert self.tryon and len(feats) == len(self.block_order)
+        res = []
+        for i, (blk, g) in enumerate(zip(self.block_order, feats)):
+            Bg, N, C = g.shape
+            if out is not None:
+                kg, vtg = out[i]
+            else:
+                kg = torch.empty(Bg * N, C, dtype=self.dtype, device=self.device)
+                vtg = torch.empty(Bg, C, N, dtype=self.dtype, device=self.device)
+            ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
+            res.append((kg, vtg))
+        return res
+
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, x, temb, ctx, B, H, W, garment_feats=None):
+    def forward(self, x, temb, ctx, B, H, W, garment_feats=None, garment_kv=None, feats_buf=None):
         """x: NHWC [B][H*W][cin_pad] (channels >= in_channels zero); temb: [B][sum Cout] (time_embeddings()[step]);
         ctx: encode_context(); garment_feats: list of [Bg][N][C] (Bg <= B; batches < B-Bg see all-zero features).
         Returns (noise NHWC [B][H*W][n_out] for TryonNet | None, exported features for GarmentNet)."""
         topo = self.topo
-        garment = dict(feats=garment_feats, idx=0)
+        garment = dict(feats=garment_feats, kv=garment_kv, feats_buf=feats_buf, idx=0)
         feats = []
         stop = None if self.tryon else self.num_features()
         h, _, _ = self._conv3(x, self.conv_in, B, H, W)

@@ -73,7 +73,9 @@ typedef struct {
     const void* res; int32_t ldr;
     int32_t mode;
     void* vt; int32_t vt_n0; int32_t vt_tokens;
-    int32_t tile_hint;           /* 0 = auto; else (BN<<16)|BM to force a tile (tests/bench) */
+    int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
+                                    128x64, 64x64; variant 1 = LDS-ring tiles 128x256 (8 waves), 128x128, 128x64, 64x64.
+                                    Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
 
@@ -107,6 +109,7 @@ typedef struct {
     int32_t k_rows[2];           /* rows per batch element in k[s] (>= nk; 0 means nk)           */
     int32_t seg_b0[2];
     float ip_scale;
+    int32_t tune;                /* 0 = auto; else (stages<<8)|waves: stages 2 (two-buffer) | 3 | 4 (LDS ring), waves 2|4|8 */
 } idmvton_attn_args;
 int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);
 

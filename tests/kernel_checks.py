@@ -66,7 +66,7 @@ def check_linear(M, N, K, dtype, dev, bias=True, res=True, rowbias=False, tile_h
     return relerr(out, ref)
 
 
-def check_geglu(M, C, dtype, dev, seed=0):
+def check_geglu(M, C, dtype, dev, seed=0, tile_hint=0):
     """GEGLU(x) = h * gelu(gate), [h | gate] = x W^T + b  (weights interleaved in 64-row blocks for the kernel)."""
     from idm_vton_amd import ops
     from idm_vton_amd.weights import interleave_geglu
@@ -78,11 +78,11 @@ def check_geglu(M, C, dtype, dev, seed=0):
     h, g = y.chunk(2, dim=-1)
     ref = h * F.gelu(g)
     wi, bi = interleave_geglu(w, b)
-    out = ops.linear(x, wi, bias=bi, geglu=True)
+    out = ops.linear(x, wi, bias=bi, geglu=True, tile_hint=tile_hint)
     return relerr(out, ref)
 
 
-def check_vt(B, Ntok, C, dtype, dev, seed=0):
+def check_vt(B, Ntok, C, dtype, dev, seed=0, tile_hint=0):
     """Fused QKV-style projection: columns [0,2C) normal, columns [2C,3C) written transposed as V^T[b][c][tok]."""
     from idm_vton_amd import ops
     M = B * Ntok
@@ -91,7 +91,7 @@ def check_vt(B, Ntok, C, dtype, dev, seed=0):
     ref = x.float() @ w.float().t()
     out = torch.zeros(M, 2 * C, dtype=dtype, device=dev)
     vt = torch.zeros(B, C, Ntok, dtype=dtype, device=dev)
-    ops.linear(x, w, out=out, vt=vt, vt_n0=2 * C, vt_tokens=Ntok)
+    ops.linear(x, w, out=out, vt=vt, vt_n0=2 * C, vt_tokens=Ntok, tile_hint=tile_hint)
     e1 = relerr(out, ref[:, : 2 * C])
     e2 = relerr(vt, ref[:, 2 * C:].reshape(B, Ntok, C).transpose(1, 2))
     return max(e1, e2)
@@ -102,7 +102,7 @@ def _nhwc(t):
 
 
 def check_conv(B, Cin, Cout, H, W, dtype, dev, k=3, stride=1, ups=False, split=0, shortcut=0, temb=False, res=False,
-               seed=0):
+               seed=0, tile_hint=0):
     """3x3 / 1x1 conv over NHWC with the fused extras of ResnetBlock2D:
     split>0  : input is cat([x1 (split ch), x2]) along C, never materialised (two pointers);
     shortcut : extra 1x1 conv of a second tensor (`shortcut` channels) fused as centre-tap K segments;
@@ -147,12 +147,12 @@ def check_conv(B, Cin, Cout, H, W, dtype, dev, k=3, stride=1, ups=False, split=0
         kw.update(res=_nhwc(rs).reshape(M, Cout))
     if len(segs) > 12:
         raise ValueError("too many segments for one launch")
-    out = ops.gemm_conv(segs, wk, M, Ho=Ho, Wo=Wo, Hi=H, Wi=W, stride=stride, ups=ups, bias=bias, **kw)
+    out = ops.gemm_conv(segs, wk, M, Ho=Ho, Wo=Wo, Hi=H, Wi=W, stride=stride, ups=ups, bias=bias, tile_hint=tile_hint, **kw)
     return relerr(out.reshape(B, Ho, Wo, Cout), _nhwc(ref))
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0):
+def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, tune=0):
     """TryonNet attn1 semantics: keys = [own N tokens ; n_garm garment tokens]; batches < b0 see all-zero garment K/V."""
     from idm_vton_amd import ops
     Cc = heads * 64
@@ -175,11 +175,11 @@ def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0):
         vv = torch.cat([vv, torch.cat([z, sp(v2)], dim=0)], dim=2)
     ref = F.scaled_dot_product_attention(sp(q), kk, vv).transpose(1, 2).reshape(B, N, Cc)
     out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
-    ops.attention(q, out, segs, heads)
+    ops.attention(q, out, segs, heads, tune=tune)
     return relerr(out, ref)
 
 
-def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, seed=0):
+def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, seed=0, tune=0):
     """IPAttnProcessor2_0 semantics: SDPA over text keys + ip_scale * SDPA over image keys."""
     from idm_vton_amd import ops
     Cc = heads * 64
@@ -198,7 +198,7 @@ def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, 
     ref = ref.transpose(1, 2).reshape(B, N, Cc)
     out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
     from idm_vton_amd import ffi
-    ops.attention(q, out, segs, heads, mode=ffi.ATTN_CROSS, ip_scale=ip_scale)
+    ops.attention(q, out, segs, heads, mode=ffi.ATTN_CROSS, ip_scale=ip_scale, tune=tune)
     return relerr(out, ref)
 
 
@@ -261,6 +261,14 @@ def check_elementwise(B, h, w, dtype, dev, seed=0):
     return max(e1, e2, e3, e4)
 
 
+def _hint(variant, bn, bm):
+    return (variant << 28) | (bn << 16) | bm
+
+
+RING_TILES = ((_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
+              (_hint(1, 64, 64), "r64x64"))
+
+
 def all_checks(dev="cuda"):
     """(name, thunk, tolerance) for every kernel-level check; sizes are the reference's real shapes where cheap."""
     out = []
@@ -271,6 +279,23 @@ def all_checks(dev="cuda"):
         add("probe_mfma", lambda dt=dt: check_probe_mfma(dt, dev), 1e-6 if dt == torch.float16 else 1e-6)
         for hint, tag in ((0, "auto"), ((128 << 16) | 128, "128x128"), ((128 << 16) | 64, "128x64"), ((64 << 16) | 64, "64x64")):
             add(f"linear_768x640x640_{tag}", lambda dt=dt, hint=hint: check_linear(768, 640, 640, dt, dev, tile_hint=hint))
+        # LDS-ring variants (tile_hint variant 1): every epilogue / gather mode on every ring tile, incl. M/N tails, K = 1
+        # and 2 tiles (shorter than the ring), and tile counts that are not multiples of the raster group
+        for hint, tag in RING_TILES:
+            add(f"ring_linear_768x640x640_{tag}", lambda dt=dt, hint=hint: check_linear(768, 640, 640, dt, dev, tile_hint=hint))
+            add(f"ring_linear_ragged_1000x328x192_{tag}", lambda dt=dt, hint=hint: check_linear(1000, 328, 192, dt, dev, rowbias=True, tile_hint=hint))
+            add(f"ring_linear_K64_{tag}", lambda dt=dt, hint=hint: check_linear(300, 192, 64, dt, dev, tile_hint=hint))
+            add(f"ring_linear_K128_{tag}", lambda dt=dt, hint=hint: check_linear(2500, 136, 128, dt, dev, tile_hint=hint))
+            add(f"ring_linear_3072x1280x1280_{tag}", lambda dt=dt, hint=hint: check_linear(3072, 1280, 1280, dt, dev, tile_hint=hint))
+            add(f"ring_vt_B2_N768_C640_{tag}", lambda dt=dt, hint=hint: check_vt(2, 768, 640, dt, dev, tile_hint=hint))
+            add(f"ring_conv3x3_320_32x24_{tag}", lambda dt=dt, hint=hint: check_conv(2, 320, 320, 32, 24, dt, dev, temb=True, tile_hint=hint))
+            add(f"ring_conv3x3_s2_{tag}", lambda dt=dt, hint=hint: check_conv(2, 128, 192, 17, 13, dt, dev, stride=2, tile_hint=hint))
+            add(f"ring_conv3x3_ups_{tag}", lambda dt=dt, hint=hint: check_conv(2, 128, 128, 9, 7, dt, dev, ups=True, tile_hint=hint))
+            add(f"ring_conv1x1_split_{tag}", lambda dt=dt, hint=hint: check_conv(2, 320, 64, 12, 10, dt, dev, k=1, split=192, tile_hint=hint))
+            add(f"ring_conv3x3_shortcut_{tag}", lambda dt=dt, hint=hint: check_conv(2, 128, 128, 16, 12, dt, dev, shortcut=192, temb=True, tile_hint=hint))
+            if (hint >> 16) & 0xfff == 128:
+                add(f"ring_geglu_1536x640_{tag}", lambda dt=dt, hint=hint: check_geglu(1536, 640, dt, dev, tile_hint=hint))
+                add(f"ring_geglu_ragged_200x64_{tag}", lambda dt=dt, hint=hint: check_geglu(200, 64, dt, dev, tile_hint=hint))
         add("linear_ragged_200x328x192", lambda dt=dt: check_linear(200, 328, 192, dt, dev, rowbias=True))
         add("linear_M4_temb", lambda dt=dt: check_linear(4, 1280, 1280, dt, dev, res=False))
         add("linear_3072x1280x1280", lambda dt=dt: check_linear(3072, 1280, 1280, dt, dev))
@@ -285,6 +310,18 @@ def all_checks(dev="cuda"):
         add("conv1x1_split_192+128", lambda dt=dt: check_conv(2, 320, 64, 12, 10, dt, dev, k=1, split=192))
         add("conv3x3_shortcut_res", lambda dt=dt: check_conv(2, 128, 128, 16, 12, dt, dev, shortcut=192, temb=True))
         add("conv3x3_res", lambda dt=dt: check_conv(1, 64, 64, 8, 8, dt, dev, res=True))
+        # every (waves, stages) instantiation of the attention kernel, incl. the LDS-ring forms (Q through LDS): ragged
+        # tails, closed-form zero segment, fewer tiles than ring stages (N16: 1+1 tiles), large logits (rescale path)
+        for nw in (2, 4, 8):
+            for stg in (2, 3, 4):
+                tn, tag = (stg << 8) | nw, f"w{nw}s{stg}"
+                add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
+                add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn))
+                add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
+                add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn))
+                add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn))
+                add(f"attn_cross_77_16_N768_{tag}", lambda dt=dt, tn=tn: check_attn_cross(4, 4, 768, dt, dev, tune=tn))
+                add(f"attn_cross_scale0.5_N200_{tag}", lambda dt=dt, tn=tn: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5, tune=tn))
         add("attn_self_1seg_N768", lambda dt=dt: check_attn_self(2, 4, 768, dt, dev))
         add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
         add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))

@@ -6,7 +6,8 @@ from tests import parity_utils as pu
 
 
 @torch.no_grad()
-def run(kind="tiny", dtype=torch.float16, B=1, H=128, W=128, steps=4, scheduler="ddpm", use_graph=False, device="cuda"):
+def run(kind="tiny", dtype=torch.float16, B=1, H=128, W=128, steps=4, scheduler="ddpm", use_graph=False, device="cuda",
+        overlap=False):
     from idm_vton_amd import ops
     from idm_vton_amd.pipeline import TryonEngine
     from oracle import pipeline as opipe
@@ -75,10 +76,20 @@ def run(kind="tiny", dtype=torch.float16, B=1, H=128, W=128, steps=4, scheduler=
     res["prep_masked_lat"] = pu.relerr(st["trace"]["masked_lat"], tr["masked_lat"][:B])
     res["prep_pose_lat"] = pu.relerr(st["trace"]["pose_lat"], tr["pose_lat"][:B])
     ptr = {}
-    lat = eng.denoise(st, use_graph=use_graph, trace=None if use_graph else ptr)
-    if not use_graph:
+    traced = not (use_graph or overlap)
+    lat = eng.denoise(st, use_graph=use_graph, trace=ptr if traced else None, overlap=overlap)
+    if traced:
         for i, (a, b) in enumerate(zip(ptr["step_latents"], tr["step_latents"])):
             res[f"latents_step{i + 1}"] = pu.relerr(a, b)
     res["latents_final"] = pu.relerr(lat, tr["step_latents"][-1])
     res["image"] = pu.relerr(eng.decode(lat), img_o)
+    if overlap:
+        # the two-stream form must reproduce the serial form bit for bit (same kernels, same order per stream); run the
+        # pipeline a second time through the already-captured graphs as well (persistent-buffer refresh path)
+        st2 = eng.prepare(num_inference_steps=steps, guidance_scale=2.0, scheduler=scheduler, **inp)
+        lat_serial = eng.denoise(st2, use_graph=False, overlap=False).clone()
+        res["overlap_vs_serial"] = pu.relerr(lat, lat_serial)
+        st3 = eng.prepare(num_inference_steps=steps, guidance_scale=2.0, scheduler=scheduler, **inp)
+        lat_again = eng.denoise(st3, use_graph=use_graph, overlap=True)
+        res["overlap_second_call"] = pu.relerr(lat_again, lat_serial)
     return res
