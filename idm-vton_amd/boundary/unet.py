@@ -46,13 +46,15 @@ def _ensure(node, path):
 def _build_tree(root, shapes, dtype, device):
     """Nested modules whose state_dict() keys are exactly `shapes`' names.  2-D weights become nn.Linear (so attributes
     like `.in_features` exist); parameters already created by pre-installed modules (Attention, Resampler) are kept."""
-    for name, shp in shapes:
+    shapes = list(shapes)
+    for name, shp in shapes:                              # pass 1: every 2-D weight becomes an nn.Linear
         parts = name.split(".")
         if len(shp) == 2 and parts[-1] == "weight":
             parent = _ensure(root, parts[:-2])
             if parts[-2] not in parent._modules:
                 parent.add_module(parts[-2], nn.Linear(shp[1], shp[0], bias=False, device=device, dtype=dtype))
-            continue
+    for name, shp in shapes:                              # pass 2: everything else (biases land on the Linears above)
+        parts = name.split(".")
         node = _ensure(root, parts[:-1])
         if node._parameters.get(parts[-1]) is not None:
             continue

@@ -1,6 +1,6 @@
 // norm.hip -- HBM-bound normalisation kernels: LayerNorm (one wave per token row, row kept in registers, two-pass
 // statistics in fp32, optional second output = GarmentNet feature export) and NHWC GroupNorm(+SiLU) as
-// stats (per-channel fp32 partials -> per-(batch,group) double atomics) + apply (16-byte vector loads/stores, the
+// stats (per-channel fp32 partials -> per-(block,batch,group) double partials, deterministic) + finalize + apply (16-byte vector loads/stores, the
 // per-thread channel chunk's scale/shift held in registers).  See include/idmvton_hip.h for the reference call sites.
 #include "common.cuh"
 
@@ -83,21 +83,22 @@ extern "C" int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream) 
 
 // ------------------------------------------------------------------------------------------------ GroupNorm (NHWC)
 // Thread -> fixed 8-channel chunk (chunk = tid % (C/8)), striding over pixels.  A chunk may straddle two groups
-// (e.g. C=320: 10 channels per group), so statistics are accumulated per CHANNEL in LDS and folded to groups at the end.
+// (e.g. C=320: 10 channels per group), so statistics are reduced per CHANNEL in LDS and folded to groups at the end.
+// The reduction is DETERMINISTIC (no atomics): fixed pixel order per thread, fixed row order across the block's pixel
+// lanes, one (sum, sumsq) partial per (block, batch, group) in HBM, folded in block order by gn_finalize_kernel.  Results
+// are therefore bit-reproducible run to run (the parity tests compare execution modes bit for bit).
 #define GN_MAXC 2560
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_args a, int pix_per_block) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_args a, int pix_per_block, int nblk) {
     typedef typename VT<T>::v8 v8;
-    __shared__ float s_sum[GN_MAXC], s_sq[GN_MAXC];
+    __shared__ float red_s[GN_MAXC], red_q[GN_MAXC];     // [pixel lane][channel] (tpp * C <= 2048) or [channel] (C > 2048)
     const int b = blockIdx.y;
     const int nchunk = a.C >> 3;
-    for (int c = threadIdx.x; c < a.C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
     const int tpp = 256 / nchunk > 0 ? 256 / nchunk : 1;   // pixels processed concurrently per pass
     const int chunk = threadIdx.x % nchunk, psub = threadIdx.x / nchunk;
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, a.HW);
-    // chunks beyond 256 threads (C > 2048): loop over chunk groups
+    // chunks beyond 256 threads (C > 2048, tpp == 1): each thread also owns chunk + 256
     for (int cb = chunk; cb < nchunk; cb += 256) {
         const int c0 = cb * 8;
         const T* src; int pitch, coff;
@@ -113,17 +114,36 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_a
                 for (int j = 0; j < 8; ++j) { const float f = (float)t[j]; s[j] += f; q[j] += f * f; }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&s_sum[c0 + j], s[j]); atomicAdd(&s_sq[c0 + j], q[j]); }
+            for (int j = 0; j < 8; ++j) { red_s[psub * a.C + c0 + j] = s[j]; red_q[psub * a.C + c0 + j] = q[j]; }
         }
     }
     __syncthreads();
+    // per-channel totals over the pixel lanes, in lane order; column c is touched by exactly one thread
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        float ss = red_s[c], qq = red_q[c];
+        for (int p = 1; p < tpp; ++p) { ss += red_s[p * a.C + c]; qq += red_q[p * a.C + c]; }
+        red_s[c] = ss; red_q[c] = qq;
+    }
+    __syncthreads();
     const int cpg = a.C / a.groups;
+    double* part = a.stats + (size_t)2 * a.B * a.groups;
     for (int g = threadIdx.x; g < a.groups; g += 256) {
         double ds = 0.0, dq = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { ds += (double)s_sum[c]; dq += (double)s_sq[c]; }
-        atomicAdd(&a.stats[((size_t)b * a.groups + g) * 2 + 0], ds);
-        atomicAdd(&a.stats[((size_t)b * a.groups + g) * 2 + 1], dq);
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { ds += (double)red_s[c]; dq += (double)red_q[c]; }
+        double* dst = part + (((size_t)b * a.groups + g) * nblk + blockIdx.x) * 2;
+        dst[0] = ds; dst[1] = dq;
     }
+}
+
+// one wave per (batch, group): block partials summed in a fixed order -> stats[(b*groups + g)*2 + {0, 1}]
+__global__ __launch_bounds__(64) void gn_finalize_kernel(double* stats, int bg, int nblk) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double* part = stats + (size_t)2 * bg + (size_t)i * nblk * 2;
+    double ds = 0.0, dq = 0.0;
+    for (int k = lane; k < nblk; k += 64) { ds += part[2 * k]; dq += part[2 * k + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+    if (lane == 0) { stats[2 * i] = ds; stats[2 * i + 1] = dq; }
 }
 
 template <typename T>
@@ -173,22 +193,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_a
     }
 }
 
-template <typename T>
-static int launch_gn(const idmvton_groupnorm_args& a, hipStream_t st) {
+static void gn_geometry(const idmvton_groupnorm_args& a, int& nblk, int& ppb) {
     // ~8 blocks per CU over the whole launch; each block owns a contiguous pixel slab of one batch element.
-    int nblk = (2048 + a.B - 1) / a.B;
-    int ppb = (a.HW + nblk - 1) / nblk;
+    nblk = (2048 + a.B - 1) / a.B;
+    ppb = (a.HW + nblk - 1) / nblk;
     const int nchunk = a.C >> 3;
     const int tpp = 256 / nchunk > 0 ? 256 / nchunk : 1;
     if (ppb < tpp * 4) ppb = tpp * 4;
     nblk = (a.HW + ppb - 1) / ppb;
+}
+
+template <typename T>
+static int launch_gn(const idmvton_groupnorm_args& a, hipStream_t st) {
+    int nblk, ppb;
+    gn_geometry(a, nblk, ppb);
     const dim3 grid(nblk, a.B), block(256);
-    hipError_t e = hipMemsetAsync(a.stats, 0, sizeof(double) * 2 * a.B * a.groups, st);
-    if (e != hipSuccess) return idmvton_set_error(IDMVTON_E_LAUNCH, "groupnorm: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((gn_stats_kernel<T>), grid, block, 0, st, a, ppb);
+    hipLaunchKernelGGL((gn_stats_kernel<T>), grid, block, 0, st, a, ppb, nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B * a.groups), dim3(64), 0, st, a.stats, a.B * a.groups, nblk);
     hipLaunchKernelGGL((gn_apply_kernel<T>), grid, block, 0, st, a, ppb);
     CHECK_LAUNCH("groupnorm");
     return IDMVTON_OK;
+}
+
+extern "C" int idmvton_groupnorm_stats_doubles(int B, int HW, int C, int groups) {
+    if (B <= 0 || HW <= 0 || C < 8 || groups <= 0) return -1;
+    idmvton_groupnorm_args a;
+    a.B = B; a.HW = HW; a.C = C; a.groups = groups;
+    int nblk, ppb;
+    gn_geometry(a, nblk, ppb);
+    return 2 * B * groups * (1 + nblk);
 }
 
 extern "C" int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream) {
@@ -197,6 +230,9 @@ extern "C" int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream) 
     CHECK_ARG(a->B > 0 && a->HW > 0 && a->C > 0 && a->groups > 0 && a->C % a->groups == 0 && a->C % 8 == 0 && a->C <= GN_MAXC,
               IDMVTON_E_SHAPE, "groupnorm: B=%d HW=%d C=%d groups=%d", a->B, a->HW, a->C, a->groups);
     CHECK_ARG(a->x && a->y && a->gamma && a->beta && a->stats, IDMVTON_E_ARG, "groupnorm: null pointer");
+    CHECK_ARG(a->stats_doubles >= idmvton_groupnorm_stats_doubles(a->B, a->HW, a->C, a->groups), IDMVTON_E_SHAPE,
+              "groupnorm: stats scratch holds %d doubles, needs %d", a->stats_doubles,
+              idmvton_groupnorm_stats_doubles(a->B, a->HW, a->C, a->groups));
     CHECK_ARG(a->C1 > 0 && a->C1 <= a->C && a->C1 % 8 == 0 && (a->C1 == a->C || a->x2), IDMVTON_E_SHAPE, "groupnorm: C1=%d", a->C1);
     CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->x2 | (uintptr_t)a->y) & 15) == 0, IDMVTON_E_ALIGN, "groupnorm: pointer alignment");
     return a->dtype == IDMVTON_BF16 ? launch_gn<bf16_t>(*a, (hipStream_t)stream) : launch_gn<f16_t>(*a, (hipStream_t)stream);

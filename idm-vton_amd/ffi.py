@@ -42,7 +42,7 @@ class LayerNormArgs(C.Structure):
 
 class GroupNormArgs(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("HW", i32), ("C", i32), ("groups", i32), ("x", vp), ("C1", i32),
-                ("x2", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("silu", i32), ("y", vp), ("stats", vp)]
+                ("x2", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("silu", i32), ("y", vp), ("stats", vp), ("stats_doubles", i32)]
 
 
 class PackInputArgs(C.Structure):
@@ -76,7 +76,7 @@ STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
-           "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma"]
+           "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles"]
 
 _lib = None
 
@@ -108,6 +108,8 @@ def lib():
         getattr(L, s).argtypes = [vp, vp]
         getattr(L, s).restype = C.c_int
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]
+    L.idmvton_groupnorm_stats_doubles.argtypes = [C.c_int] * 4
+    L.idmvton_groupnorm_stats_doubles.restype = C.c_int
     _lib = L
     return L
 

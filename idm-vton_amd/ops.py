@@ -176,7 +176,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, out2=None):
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu, stats, x2=None, out=None):
-    """x: [B][HW][C1] (+ optional x2 [B][HW][C2], virtually concatenated along C); stats: float64 [B*groups*2]."""
+    """x: [B][HW][C1] (+ optional x2 [B][HW][C2], virtually concatenated along C); stats: float64 scratch of at least
+    gn_stats_doubles(B, HW, C, groups) elements (GN_STATS_DOUBLES covers every shape with B <= 64, groups <= 32)."""
     B, HW, C1 = x.shape
     Cc = C1 + (x2.shape[-1] if x2 is not None else 0)
     if out is None:
@@ -185,9 +186,16 @@ def groupnorm(x, gamma, beta, groups, eps, silu, stats, x2=None, out=None):
     a.dtype, a.B, a.HW, a.C, a.groups = _dt(x), B, HW, Cc, groups
     a.x, a.C1, a.x2 = _ptr(x), C1, _ptr(x2)
     a.gamma, a.beta, a.eps, a.silu = _ptr(gamma), _ptr(beta), eps, int(bool(silu))
-    a.y, a.stats = _ptr(out), _ptr(stats)
+    a.y, a.stats, a.stats_doubles = _ptr(out), _ptr(stats), stats.numel()
     _call("idmvton_groupnorm", a, bytes_=3.0 * B * HW * Cc * x.element_size())
     return out
+
+
+GN_STATS_DOUBLES = 2 * 32 * (2048 + 2 * 64 + 64)
+
+
+def gn_stats_doubles(B, HW, C, groups):
+    return ffi.lib().idmvton_groupnorm_stats_doubles(B, HW, C, groups)
 
 
 def pack_input(latents, cond, out):

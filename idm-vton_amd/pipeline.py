@@ -193,7 +193,7 @@ class TryonEngine:
     @torch.no_grad()
     def denoise(self, st, use_graph=False, trace=None, overlap=False):
         n = len(st["timesteps"])
-        if overlap and trace is None:
+        if overlap:
             return self._denoise_overlap_graph(st) if use_graph else self._denoise_overlap_eager(st)
         if not use_graph:
             for i in range(n):
@@ -226,6 +226,8 @@ class TryonEngine:
             if nz is not None:
                 nz.copy_(st["steps_noise"][i])
             graph.replay()
+            if trace is not None:
+                trace.setdefault("step_latents", []).append(sst["latents"].clone())
         return sst["latents"]
 
     @torch.no_grad()

@@ -57,7 +57,7 @@ class HipUNet:
         self.tryon = cfg.mode == "tryon"
         self.cin_pad = _pad64(cfg.in_channels)
         self._prep()
-        self._gn_stats = torch.empty(64 * 64 * 2, dtype=torch.float64, device=self.device)
+        self._gn_stats = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=self.device)
         self._ctx = None
 
     # ------------------------------------------------------------------------------------------------ weight prep

@@ -19,7 +19,7 @@ class HipVAE:
         self.sd = sd
         boc, L = cfg.block_out_channels, cfg.layers_per_block
         self.convs = {}
-        self._gn_stats = torch.empty(64 * 64 * 2, dtype=torch.float64, device=self.device)
+        self._gn_stats = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=self.device)
 
         def res(p, cin, cout):
             self.convs[p + ".conv1"] = _Conv(sd, p + ".conv1")

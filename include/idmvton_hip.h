@@ -128,12 +128,13 @@ typedef struct {
 int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * idmvton_groupnorm : NHWC GroupNorm (+ optional SiLU), fp32/fp64 statistics.  Two launches inside one call:
- * stats (sum, sum-of-squares per (b, group) accumulated in double) then apply.  The input may be the channel-concat
+ * idmvton_groupnorm : NHWC GroupNorm (+ optional SiLU), fp32/fp64 statistics.  Three launches inside one call:
+ * stats (per-block sum / sum-of-squares partials, no atomics: bit-reproducible), finalize (block-order fold), apply.  The input may be the channel-concat
  * of two tensors (x: C1 channels, x2: C-C1 channels) -- the torch.cat of skip connections is never materialised.
  * Replaces nn.GroupNorm (+F.silu) in diffusers ResnetBlock2D (eps 1e-5; src/unet_hacked_tryon.py:325,606),
  * Transformer2DModel.norm (eps 1e-6; src/transformerhacked_tryon.py:148,329), conv_norm_out (:1383-1385), VAE norms.
- * `stats` is caller-owned scratch of B*groups*2 doubles; it is zeroed by the call (memset node on the stream).
+ * `stats` is caller-owned scratch of idmvton_groupnorm_stats_doubles(B, HW, C, groups) doubles (its capacity goes in
+ * `stats_doubles`); it needs no initialisation.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t dtype; int32_t B, HW, C, groups;
@@ -141,9 +142,10 @@ typedef struct {
     const void* x2;
     const void* gamma; const void* beta; float eps; int32_t silu;
     void* y;                    /* [B][HW][C] */
-    double* stats;
+    double* stats; int32_t stats_doubles;
 } idmvton_groupnorm_args;
 int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream);
+int idmvton_groupnorm_stats_doubles(int B, int HW, int C, int groups);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Small fused elementwise ops of the loop body (src/tryon_pipeline.py:1769-1823).

@@ -2,6 +2,8 @@
 
   resampler_ref.safetensors  -- weights, input and output of the REFERENCE's own ip_adapter/resampler.py imported verbatim
                                 (the one hot-path file that imports without diffusers): pins oracle/resampler.py.
+  reference_signatures.json  -- argument lists of the reference's call surface for this path (ast-parsed): pins the
+                                drop-in boundary (tests/test_boundary_cpu.py).
   tiny_pipeline.safetensors  -- oracle outputs (garment features, TryonNet eps, per-step latents, image) of the tiny
                                 config on seeded inputs: regression pin for the oracle itself and the golden target of
                                 the GPU parity tests (tests/test_golden_gpu.py).  Parity vs the reference is UNPINNED for
@@ -57,8 +59,45 @@ def tiny_pipeline_fixture():
                                   "weights rounded to fp16, inputs make_inputs(seed=42)", "generator": "oracle/make_golden.py"})
 
 
+REF_API = {
+    "ip_adapter/attention_processor.py": {"AttnProcessor2_0": ["__init__", "__call__"], "IPAttnProcessor2_0": ["__init__", "__call__"]},
+    "ip_adapter/resampler.py": {"Resampler": ["__init__", "forward"]},
+    "src/unet_hacked_tryon.py": {"UNet2DConditionModel": ["forward", "set_attn_processor"]},
+    "src/unet_hacked_garmnet.py": {"UNet2DConditionModel": ["forward", "set_attn_processor"]},
+    "src/tryon_pipeline.py": {"StableDiffusionXLInpaintPipeline": ["__init__", "encode_image", "prepare_ip_adapter_image_embeds",
+                                                                   "encode_prompt", "check_inputs", "__call__"]},
+}
+
+
+def reference_signatures(root="/root/reference"):
+    """Argument names (in order) of the reference's call surface for this path, read with `ast` (the modules themselves
+    cannot be imported here: they import diffusers).  SURVEY.md 8b lists these as the drop-in contract."""
+    import ast
+    out = {}
+    for rel, wanted in REF_API.items():
+        tree = ast.parse(open(os.path.join(root, rel)).read())
+        for node in tree.body:
+            if isinstance(node, ast.ClassDef) and node.name in wanted:
+                for f in node.body:
+                    if isinstance(f, ast.FunctionDef) and f.name in wanted[node.name]:
+                        a = f.args
+                        names = [x.arg for x in a.posonlyargs + a.args] + (["*" + a.vararg.arg] if a.vararg else [])
+                        names += [x.arg for x in a.kwonlyargs] + (["**" + a.kwarg.arg] if a.kwarg else [])
+                        out[f"{rel}:{node.name}.{f.name}"] = dict(line=f.lineno, args=names)
+    return out
+
+
+def signatures_fixture():
+    import json
+    with open(os.path.join(OUT, "reference_signatures.json"), "w") as f:
+        json.dump(reference_signatures(), f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    signatures_fixture()
+    if "--signatures-only" in sys.argv:
+        sys.exit(0)
     resampler_fixture()
     tiny_pipeline_fixture()
     print("wrote", os.listdir(OUT))

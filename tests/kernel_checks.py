@@ -222,12 +222,23 @@ def check_groupnorm(B, HW, Cc, dtype, dev, groups=32, silu=True, split=0, eps=1e
     ref = F.group_norm(x.float().transpose(1, 2), groups, g.float(), b.float(), eps).transpose(1, 2)
     if silu:
         ref = F.silu(ref)
-    stats = torch.empty(B * groups * 2, dtype=torch.float64, device=dev)
+    stats = torch.empty(ops.gn_stats_doubles(B, HW, Cc, groups), dtype=torch.float64, device=dev)
     if split:
         out = ops.groupnorm(x[..., :split].contiguous(), g, b, groups, eps, silu, stats, x2=x[..., split:].contiguous())
     else:
         out = ops.groupnorm(x, g, b, groups, eps, silu, stats)
     return relerr(out, ref)
+
+
+def check_groupnorm_reproducible(B, HW, Cc, dtype, dev, groups=32):
+    """GroupNorm statistics are reduced without atomics: two runs on the same input give identical bits (returns 0.0)."""
+    from idm_vton_amd import ops
+    x = _r(B, HW, Cc, dtype=dtype, dev=dev, scale=2.0, seed=11) + 0.7
+    g = _r(Cc, dtype=dtype, dev=dev, seed=12)
+    b = _r(Cc, dtype=dtype, dev=dev, seed=13)
+    stats = torch.full((ops.gn_stats_doubles(B, HW, Cc, groups),), float("nan"), dtype=torch.float64, device=dev)   # scratch needs no init
+    outs = [ops.groupnorm(x, g, b, groups, 1e-5, True, stats).clone() for _ in range(3)]
+    return 0.0 if all(torch.equal(outs[0], o) for o in outs[1:]) else 1.0
 
 
 def check_elementwise(B, h, w, dtype, dev, seed=0):
@@ -337,5 +348,7 @@ def all_checks(dev="cuda"):
         add("groupnorm_1920_split1280", lambda dt=dt: check_groupnorm(2, 300, 1920, dt, dev, split=1280))
         add("groupnorm_2560_split1280", lambda dt=dt: check_groupnorm(2, 192, 2560, dt, dev, split=1280))
         add("groupnorm_128_nosilu_eps1e-6", lambda dt=dt: check_groupnorm(1, 4096, 128, dt, dev, silu=False, eps=1e-6))
+        add("groupnorm_reproducible_320", lambda dt=dt: check_groupnorm_reproducible(4, 12288, 320, dt, dev), 0.0)
+        add("groupnorm_reproducible_2560", lambda dt=dt: check_groupnorm_reproducible(2, 768, 2560, dt, dev), 0.0)
         add("elementwise", lambda dt=dt: check_elementwise(2, 16, 12, dt, dev))
     return out

@@ -112,7 +112,7 @@ def main():
         if flt and flt not in name:
             continue
         x, g, b = r(B, HW, C), r(C), r(C)
-        st = torch.empty(B * 64, dtype=torch.float64, device=dev)
+        st = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=dev)
         out = torch.empty_like(x)
         rec(name, timeit(lambda: ops.groupnorm(x, g, b, 32, 1e-5, True, st, out=out)), bytes_=3.0 * B * HW * C * 2)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

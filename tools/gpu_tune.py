@@ -128,6 +128,8 @@ def main():
             if t < best_t * 0.97:                        # switch away from the default only for a >= 3% win
                 best_name, best_val, best_t = name, val, t
         setattr(a, field, 0)
+        for o, r in zip(outs, refs):                         # later signatures read these tensors as inputs
+            o.copy_(r)
         row["best"] = best_name
         row["best_us"] = round(best_t, 2)
         if best_val:
