@@ -137,6 +137,8 @@ class _UNetBase(nn.Module):
         from safetensors.torch import save_file
         os.makedirs(save_directory, exist_ok=True)
         c = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.config).items()}
+        # not diffusers config keys: the Resampler geometry (train_xl.py:341-352 hard-codes it; absent => those defaults)
+        c["resampler"], c["ip_num_tokens"] = dict(self.cfg.resampler), self.cfg.ip_num_tokens
         c["_class_name"] = "UNet2DConditionModel"
         json.dump(c, open(os.path.join(save_directory, "config.json"), "w"), indent=1)
         save_file({k: v.contiguous().cpu() for k, v in self.state_dict().items()},

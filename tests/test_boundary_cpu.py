@@ -106,7 +106,7 @@ def test_unet_attribute_surface_and_state_dict_keys():
     t.set_attn_processor(procs)
 
 
-def test_from_pretrained_round_trip(tmp_path):
+def _round_trip(tmp_path):
     from idm_vton_amd.boundary.scheduler import DDPMScheduler
     from src.tryon_pipeline import StableDiffusionXLInpaintPipeline
     from src.unet_hacked_garmnet import UNet2DConditionModel as G
@@ -135,8 +135,12 @@ def test_from_pretrained_round_trip(tmp_path):
     return pipe
 
 
+def test_from_pretrained_round_trip(tmp_path):
+    _round_trip(tmp_path)
+
+
 def test_pipeline_argument_errors_and_no_cpu_path(tmp_path):
-    pipe = test_from_pretrained_round_trip(tmp_path)
+    pipe = _round_trip(tmp_path)
     B, H, W = 1, 128, 128
     z = lambda *s: torch.zeros(*s)
     kw = dict(prompt_embeds=z(B, 77, 128), negative_prompt_embeds=z(B, 77, 128), pooled_prompt_embeds=z(B, 64),
