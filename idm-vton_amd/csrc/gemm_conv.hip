@@ -39,7 +39,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool LIN, bool PF, bool TR>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
@@ -177,7 +177,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     };
 
     const int nt = p.Ktot >> 6;
-    if constexpr (ST == 2) {
+    if constexpr (!V1) {
         issue(0, 0);
         for (int t = 0; t < nt; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -239,21 +239,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         if (m >= p.M) continue;
         const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
         if (p.mode == IDMVTON_EPI_GEGLU) {
-            if constexpr (NI == 2) {
+            if constexpr (NI % 2 == 0) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nh = n0 + wn * SN + 8 * g + 4 * u;          // h rows; gate rows are nh + 32
-                    if (nh + 32 >= p.N) continue;
-                    const int jo = ((n0 + wn * SN) >> 1) + 8 * g + 4 * u;
-                    v4 o;
+                for (int pr = 0; pr < NI / 2; ++pr)          // 64-row weight blocks [32 h | 32 gate] of this wave
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float h = acc[0][mi][4 * g + j], gt = acc[1][mi][4 * g + j];
-                        if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
-                        o[j] = (T)(h * gelu_erf(gt));
+                    for (int g = 0; g < 4; ++g) {
+                        const int nh = n0 + wn * SN + pr * 64 + 8 * g + 4 * u;     // h rows; gate rows are nh + 32
+                        if (nh + 32 >= p.N) continue;
+                        const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 8 * g + 4 * u;
+                        v4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float h = acc[2 * pr][mi][4 * g + j], gt = acc[2 * pr + 1][mi][4 * g + j];
+                            if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
+                            o[j] = (T)(h * gelu_erf(gt));
+                        }
+                        *(v4*)(out + (size_t)m * p.ldo + jo) = o;
                     }
-                    *(v4*)(out + (size_t)m * p.ldo + jo) = o;
-                }
             }
             continue;
         }
@@ -295,14 +297,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 
 // Tile configurations.  id = the `variant` field of tile_hint (bits 28..31); BN/BM in bits 16..27 / 0..15.
 //   v0 (ST=2, 4 waves): 128x128, 128x64, 64x64           -- 2-3 blocks per CU hide the load latency
-//   v1 (ring)         : 128x256 8 waves ST=3 (144 KiB, 1 block/CU), 128x128 4 waves ST=3 (96 KiB),
+//   v1 (ring)         : 256x256 8 waves ST=2 (128 KiB, 32 B/clk/CU of operand traffic at MFMA peak),
+//                       128x256 8 waves ST=3 (144 KiB, 1 block/CU), 128x128 4 waves ST=3 (96 KiB),
 //                       128x64 4 waves ST=3 (72 KiB, 2 blocks/CU), 64x64 4 waves ST=4 (64 KiB, 2 blocks/CU)
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool LIN, int OCC>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC>
 __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tm, tn;
-    if constexpr (ST == 2) { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
+    if constexpr (!V1) { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
     else {
         // grouped raster: the ~32-64 tiles an XCD runs concurrently form a ~1024 x 1024 output patch (GM m-tiles tall), so
         // the operand rows they share stay in that XCD's 4 MiB L2 instead of being re-fetched per tile row
@@ -314,17 +317,17 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
         tn = rem / gsz; tm = first + (rem - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, LIN, OCC == 1, true>(p, smem, m0, n0);   // block-uniform
-    else gemm_body<T, BN, BM, WN, WM, ST, LIN, OCC == 1, false>(p, smem, m0, n0);
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1, true>(p, smem, m0, n0);   // block-uniform
+    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1, false>(p, smem, m0, n0);
 }
 
-template <typename T, int BN, int BM, int WN, int WM, int ST, int OCC>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC>
 static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
-    if constexpr (ST > 2) {                              // the ST == 2 kernels keep the one general loader
-        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, OCC>), grid, block, 0, st, p); return; }
+    if constexpr (V1) {                                  // the v0 kernels keep the one general loader
+        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, true, OCC>), grid, block, 0, st, p); return; }
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, false, OCC>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC>), grid, block, 0, st, p);
 }
 
 template <typename T>
@@ -333,15 +336,16 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tiles_m = (p.M + bm - 1) / bm;
     if (variant == 0) {
-        if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 2, 2>(p, lin, st);
-        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 2, 3>(p, lin, st);
-        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 2, 3>(p, lin, st);
+        if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 2, false, 2>(p, lin, st);
+        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 2, false, 3>(p, lin, st);
+        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 2, false, 3>(p, lin, st);
         else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v0 tile %dx%d", bn, bm);
     } else if (variant == 1) {
-        if (bn == 128 && bm == 256) launch_cfg<T, 128, 256, 2, 4, 3, 2>(p, lin, st);
-        else if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 3, 1>(p, lin, st);
-        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, 2>(p, lin, st);
-        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, 2>(p, lin, st);
+        if (bn == 256 && bm == 256) launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);
+        else if (bn == 128 && bm == 256) launch_cfg<T, 128, 256, 2, 4, 3, true, 2>(p, lin, st);
+        else if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 3, true, 1>(p, lin, st);
+        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, true, 2>(p, lin, st);
+        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, true, 2>(p, lin, st);
         else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v1 tile %dx%d", bn, bm);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
@@ -403,7 +407,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
         else if (tiles(128, 64) >= 384 || geglu) { bn = 128; bm = 64; }
         else { bn = 64; bm = 64; }
     }
-    if (geglu) CHECK_ARG(bn == 128, IDMVTON_E_ARG, "gemm_conv: GEGLU needs BN=128");
+    if (geglu) CHECK_ARG(bn >= 128, IDMVTON_E_ARG, "gemm_conv: GEGLU needs BN >= 128 (64-row wave tiles)");
     if (a->vt) CHECK_ARG(a->vt_n0 % bn == 0, IDMVTON_E_ARG, "gemm_conv: vt_n0 %% BN != 0");
     const idmvton_seg& s0 = a->seg[0];
     const bool lin = a->nseg == 1 && a->Ho == 1 && a->Hi == 1 && a->Wo == a->M && a->Wi == a->M && a->stride == 1 &&

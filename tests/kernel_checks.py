@@ -276,7 +276,7 @@ def _hint(variant, bn, bm):
     return (variant << 28) | (bn << 16) | bm
 
 
-RING_TILES = ((_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
+RING_TILES = ((_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))
 
 
@@ -304,7 +304,7 @@ def all_checks(dev="cuda"):
             add(f"ring_conv3x3_ups_{tag}", lambda dt=dt, hint=hint: check_conv(2, 128, 128, 9, 7, dt, dev, ups=True, tile_hint=hint))
             add(f"ring_conv1x1_split_{tag}", lambda dt=dt, hint=hint: check_conv(2, 320, 64, 12, 10, dt, dev, k=1, split=192, tile_hint=hint))
             add(f"ring_conv3x3_shortcut_{tag}", lambda dt=dt, hint=hint: check_conv(2, 128, 128, 16, 12, dt, dev, shortcut=192, temb=True, tile_hint=hint))
-            if (hint >> 16) & 0xfff == 128:
+            if (hint >> 16) & 0xfff >= 128:
                 add(f"ring_geglu_1536x640_{tag}", lambda dt=dt, hint=hint: check_geglu(1536, 640, dt, dev, tile_hint=hint))
                 add(f"ring_geglu_ragged_200x64_{tag}", lambda dt=dt, hint=hint: check_geglu(200, 64, dt, dev, tile_hint=hint))
         add("linear_ragged_200x328x192", lambda dt=dt: check_linear(200, 328, 192, dt, dev, rowbias=True))

@@ -12,7 +12,7 @@ DT, DEV = torch.float16, "cuda"
 
 
 def _rel(x, ref):
-    x, ref = x.float(), ref.float()
+    x, ref = x.float().cpu(), ref.float().cpu()
     assert torch.isfinite(x).all()
     return ((x - ref).abs().max() / ref.abs().max()).item()
 
