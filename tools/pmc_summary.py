@@ -19,26 +19,43 @@ def short(name):
 
 
 def main():
-    agg = {}
+    """Two aggregates: every dispatch of the run, and (key `denoise_step`) only the dispatches between the first
+    pack_input_kernel and the last cfg_step_kernel of the (serial, eager) run = the launches of the denoising steps, the
+    set bench.py's roofline leg covers."""
+    agg, step = {}, {}
     for d in sys.argv[1:]:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f, newline="") as fh:
                 rd = csv.DictReader(fh)
                 cols = {c.lower(): c for c in rd.fieldnames}
-                kn, cn, cv = cols["kernel_name"], cols["counter_name"], cols["counter_value"]
-                for row in rd:
-                    a = agg.setdefault(short(row[kn]), {}).setdefault(row[cn], [0, 0.0])
+                kn, cn, cv, di = cols["kernel_name"], cols["counter_name"], cols["counter_value"], cols["dispatch_id"]
+                rows = sorted(((int(r[di]), short(r[kn]), r[cn], float(r[cv])) for r in rd), key=lambda t: t[0])
+            lo = min((t[0] for t in rows if t[1] == "pack_input_kernel"), default=None)
+            hi = max((t[0] for t in rows if t[1] == "cfg_step_kernel"), default=None)
+            for did, k, c, v in rows:
+                a = agg.setdefault(k, {}).setdefault(c, [0, 0.0])
+                a[0] += 1
+                a[1] += v
+                if lo is not None and hi is not None and lo <= did <= hi:
+                    a = step.setdefault(k, {}).setdefault(c, [0, 0.0])
                     a[0] += 1
-                    a[1] += float(row[cv])
+                    a[1] += v
     out = {}
     for k, cs in agg.items():
         e = {c: dict(dispatches=n, mean=s / n) for c, (n, s) in cs.items()}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024.0
         out[k] = e
-    res = {"per_kernel": out}
-    if "gemm_conv_kernel" in out and "hbm_bytes_per_launch" in out["gemm_conv_kernel"]:
-        res["gemm_conv_bytes_per_launch"] = out["gemm_conv_kernel"]["hbm_bytes_per_launch"]
+    res = {"per_kernel": out, "denoise_step": {}}
+    for k, cs in step.items():
+        e = {c: dict(dispatches=n, mean=s_ / n) for c, (n, s_) in cs.items()}
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024.0
+        res["denoise_step"][k] = e
+    g = res["denoise_step"].get("gemm_conv_kernel", {})
+    if "hbm_bytes_per_launch" in g:
+        res["gemm_conv_bytes_per_launch"] = g["hbm_bytes_per_launch"]
+        res["gemm_conv_launches_counted"] = g["FETCH_SIZE"]["dispatches"]
     json.dump(res, sys.stdout, indent=1, sort_keys=True)
 
 
