@@ -119,7 +119,14 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))
-    _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot)
+    seen, xbytes = set(), 0                               # algorithmic bytes: every distinct operand tensor once
+    for sg in segs:
+        if sg.t.data_ptr() not in seen:
+            seen.add(sg.t.data_ptr())
+            xbytes += sg.t.numel() * sg.t.element_size()
+    esz = w.element_size()
+    obytes = (M * (N // 2 if geglu else N)) * esz + (M * N * esz if res is not None else 0)
+    _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
 
 
