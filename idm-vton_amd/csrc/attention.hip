@@ -253,15 +253,224 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn64_kernel: SELF mode, 4 waves x 64 query rows (two 32-row q-blocks per wave), LDS ring.  Every K fragment read from LDS
+// feeds two MFMAs (one per q-block), and the two q-blocks' chains are independent: while one block's online softmax runs on
+// the VALU, the other block's QK^T / PV MFMAs keep the matrix pipe busy from the same wave (1 wave per SIMD per workgroup).
+template <typename T, int ST>
+__global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
+    typedef typename VT<T>::v8 v8;
+    typedef typename VT<T>::v4 v4;
+    constexpr int NW = 4, QB = 256, IPW = 4;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + NW * 8192];   // [stage][K | V^T] + per-wave Q (64 rows)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
+    const int u = lane >> 5, l31 = lane & 31;
+    const int wg = xcd_remap(blockIdx.x, p.nqb * p.heads * p.B);
+    const int bh = wg / p.nqb, qb = wg - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int row0 = qb * QB + wave * 64;
+
+    {   // Q tile of this wave: 64 rows x 128 B -> LDS (8 DMA instructions, K's swizzle)
+        const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(p.q, p.qbytes);
+        char* dq = smem + ST * 16384 + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int R = i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            int row = row0 + R;
+            row = row < p.Nq ? row : p.Nq - 1;
+            dma16(rs_q, dq + i * 1024, (uint32_t)((((size_t)b * p.Nq + row) * p.ldq + h * 64 + c * 8) * 2));
+        }
+    }
+    const bool pres0 = p.nseg > 0 && b >= p.seg_b0[0];
+    const bool pres1 = p.nseg > 1 && b >= p.seg_b0[1];
+    const int nt0 = pres0 ? (p.nk[0] + 63) >> 6 : 0;
+    const int nt1 = pres1 ? (p.nk[1] + 63) >> 6 : 0;
+    const int nt = nt0 + nt1;
+
+    const int lrow = lane >> 3, lslot = lane & 7;
+    auto issue = [&](int t, int buf) {
+        const int sg = t < nt0 ? 0 : 1;
+        const int kt = sg ? t - nt0 : t;
+        const int nk = p.nk[sg];
+        const int bsg = b - p.seg_b0[sg];
+        char* dst = smem + buf * 16384 + wave * (IPW * 1024);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int j = wave * IPW + i;               // wave-uniform: 0..7 -> K rows, 8..15 -> V^T rows
+            const int R = (j & 7) * 8 + lrow;
+            const int c = lslot ^ ((R >> 1) & 7);
+            if (j < 8) {
+                const int key = kt * 64 + R;
+                const uint32_t off = (uint32_t)((((size_t)bsg * p.krows[sg] + key) * p.ldk[sg] + h * 64 + c * 8) * 2);
+                dma16(make_rsrc(p.k[sg], p.kbytes[sg]), dst + i * 1024, key < nk ? off : OOB_SENTINEL);
+            } else {
+                const int key0 = kt * 64 + c * 8;
+                const uint32_t off = (uint32_t)((((size_t)bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + key0) * 2);
+                dma16(make_rsrc(p.vt[sg], p.vtbytes[sg]), dst + i * 1024, key0 < nk ? off : OOB_SENTINEL);
+            }
+        }
+    };
+
+    int k_addr[2], k_swz[2], v_addr[2], v_swz[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; k_addr[kb] = r * 128; k_swz[kb] = (r >> 1) & 7; }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { const int r = db * 32 + l31; v_addr[db] = 8192 + r * 128 + u * 8; v_swz[db] = (r >> 1) & 7; }
+
+    const float cs = 0.125f * 1.44269504088896341f;
+    f32x16 oacc[2][2];
+    float m_run[2], l_run[2];
+    int nz = 0;                                           // closed form for absent (all-zero) segments
+    if (p.nseg > 0 && !pres0) nz += p.nk[0];
+    if (p.nseg > 1 && !pres1) nz += p.nk[1];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qi][db][r] = 0.f;
+        m_run[qi] = nz > 0 ? 0.f : NEG_BIG;
+        l_run[qi] = (nz > 0 && u == 0) ? (float)nz : 0.f;
+    }
+
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nt) issue(s, s);
+    if (nt >= ST - 1) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();      // Q (oldest DMAs, own rows) has landed
+    v8 qf[2][4];
+    {
+        const char* dq = smem + ST * 16384 + wave * 8192 + l31 * 128;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[qi][s] = *(const v8*)(dq + qi * 4096 + (((2 * s + u) ^ ((l31 >> 1) & 7)) << 4));
+    }
+
+    int cbuf = 0, ibuf = ST - 1;
+    for (int t = 0; t < nt; ++t) {
+        if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * IPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + ST - 1 < nt) issue(t + ST - 1, ibuf);
+        const char* buf = smem + cbuf * 16384;
+        cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
+        ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
+        const int sg = t < nt0 ? 0 : 1;
+        const int kt = sg ? t - nt0 : t;
+        const int valid = p.nk[sg] - kt * 64;
+
+        // ---- S^T = K . Q^T for both q-blocks (each K fragment read once) ----
+        f32x16 sacc[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qi][kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v8 kf = *(const v8*)(buf + k_addr[kb] + (((2 * s + u) ^ k_swz[kb]) << 4));
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi) sacc[qi][kb] = VT<T>::mfma(kf, qf[qi][s], sacc[qi][kb]);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            if (valid < 64) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * u;
+                        if (key >= valid) sacc[qi][kb][r] = NEG_BIG;
+                    }
+            }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qi][kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qi], mx * cs);
+            const bool grew = m_new > m_run[qi];
+            float psum = 0.f;
+            v8 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[qi][kb][r], cs, -m_new));
+                    psum += pv;
+                    pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
+                }
+            if (__any(grew)) {                           // otherwise alpha == 1 exactly for every lane
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+                l_run[qi] *= alpha;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
+            }
+            m_run[qi] = m_new;
+            l_run[qi] += psum;
+            // ---- O^T += V^T . P^T ----
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const v4 lo = *(const v4*)(buf + v_addr[db] + (((2 * ks) ^ v_swz[db]) << 4));
+                    const v4 hi = *(const v4*)(buf + v_addr[db] + (((2 * ks + 1) ^ v_swz[db]) << 4));
+                    v8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                    oacc[qi][db] = VT<T>::mfma(vf, pf[ks], oacc[qi][db]);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const float lt = l_run[qi] + __shfl_xor(l_run[qi], 32);
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+        const int q_row = row0 + qi * 32 + l31;
+        if (q_row < p.Nq) {
+            T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 4 * u;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (T)(oacc[qi][db][4 * g + j] * inv);
+                    *(v4*)(op + db * 32 + 8 * g) = o;
+                }
+        }
+    }
+}
+
 template <typename T, int MODE>
 static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
-    // tune = (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring.
+    // tune = (rows64 << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
+    // rows64 = 1: 64 query rows per wave (attn64_kernel).
     const long rows = (long)p.B * p.heads * p.Nq;
     int nw = 4, stg = 2;
     if (rows / 128 < 512) nw = 2;
     if (rows / 128 >= 2048) nw = 8;
     if (tune) { nw = tune & 0xff; stg = (tune >> 8) & 0xff; }
+    if ((tune >> 16) & 0xff) {                           // 64-row waves (attn64_kernel): SELF mode, 4 waves, ring
+        if (MODE != IDMVTON_ATTN_SELF || nw != 4 || (stg != 3 && stg != 4))
+            return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: 64-row waves need SELF mode, 4 waves, 3 or 4 stages");
+        p.nqb = (p.Nq + 255) / 256;
+        const dim3 grid64(p.nqb * p.heads * p.B), block64(256);
+        if (stg == 3) hipLaunchKernelGGL((attn64_kernel<T, 3>), grid64, block64, 0, st, p);
+        else hipLaunchKernelGGL((attn64_kernel<T, 4>), grid64, block64, 0, st, p);
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
     const int qbs = 32 * nw;
     p.nqb = (p.Nq + qbs - 1) / qbs;
     const dim3 grid(p.nqb * p.heads * p.B), block(nw * 64);
