@@ -137,6 +137,8 @@ class TryonEngine:
         return st["latents"]
 
     def _denoise_overlap_graph(self, st):
+        # (captures use capture_error_mode="thread_local": with torch.distributed/RCCL initialised a watchdog thread polls
+        # events, which the default global mode would treat as a capture violation)
         """hipGraph form of the two-stream loop: per parity one graph with two parallel branches {TryonNet step i on set p |
         GarmentNet step i+1 into set p^1}, plus a TryonNet-only graph for the last step.  Consecutive graph launches are
         ordered on the launching stream, which is exactly the dependency the two sets need."""
@@ -160,7 +162,7 @@ class TryonEngine:
             pair, last = {}, {}
             for par in (0, 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     cap = torch.cuda.current_stream()
                     side.wait_stream(cap)                            # fork
                     with torch.cuda.stream(side):
@@ -169,7 +171,7 @@ class TryonEngine:
                     cap.wait_stream(side)                            # join
                 pair[par] = g
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
+                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._tryon_main(st, tt, cf, nz, sets[par])
                 last[par] = g2
             st["latents"].copy_(saved)
@@ -215,7 +217,7 @@ class TryonEngine:
             torch.cuda.current_stream().wait_stream(side)
             st["latents"].copy_(saved)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 self._step(st, tt, tg, cf, nz)
             self._graphs[key] = (graph, st, tt, tg, cf, nz)
         graph, sst, tt, tg, cf, nz = self._graphs[key]
