@@ -137,11 +137,11 @@ class TryonEngine:
         return st["latents"]
 
     def _denoise_overlap_graph(self, st):
-        # (captures use capture_error_mode="thread_local": with torch.distributed/RCCL initialised a watchdog thread polls
-        # events, which the default global mode would treat as a capture violation)
         """hipGraph form of the two-stream loop: per parity one graph with two parallel branches {TryonNet step i on set p |
         GarmentNet step i+1 into set p^1}, plus a TryonNet-only graph for the last step.  Consecutive graph launches are
-        ordered on the launching stream, which is exactly the dependency the two sets need."""
+        ordered on the launching stream, which is exactly the dependency the two sets need.  Captures use
+        capture_error_mode="thread_local": with torch.distributed / RCCL initialised a watchdog thread polls events, which
+        the default global mode would treat as a capture violation."""
         n = len(st["timesteps"])
         has_noise = st["steps_noise"] is not None
         key = (st["B"], st["h"], st["w"], has_noise, "overlap")
