@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = xhalf_max(mx);
         const float m_new = fmaxf(m_run, mx * cs);
         const bool grew = m_new > m_run;
         float psum = 0.f;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
             }
         if (MODE == IDMVTON_ATTN_CROSS) {
             if (t == nt0 - 1) {                          // end of the text group: finalise it and restart the softmax
-                const float lt = l_run + __shfl_xor(l_run, 32);
+                const float lt = xhalf_sum(l_run);
                 const float inv = 1.0f / lt;
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     }
 
     // ---- finalise and store: lane holds O[q][h*64 + db*32 + 8g + 4u + j] ----
-    const float lt = l_run + __shfl_xor(l_run, 32);
+    const float lt = xhalf_sum(l_run);
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     const float sc = MODE == IDMVTON_ATTN_CROSS ? p.ip_scale * inv : inv;
     if (q_row < p.Nq) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qi][kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xhalf_max(mx);
             const float m_new = fmaxf(m_run[qi], mx * cs);
             const bool grew = m_new > m_run[qi];
             float psum = 0.f;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
 
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        const float lt = l_run[qi] + __shfl_xor(l_run[qi], 32);
+        const float lt = xhalf_sum(l_run[qi]);
         const float inv = lt > 0.f ? 1.0f / lt : 0.f;
         const int q_row = row0 + qi * 32 + l31;
         if (q_row < p.Nq) {

@@ -58,6 +58,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Exchange between the two 32-lane halves of a wave without the LDS crossbar (v_permlane32_swap: lanes 32-63 of the first
+// operand swap with lanes 0-31 of the second): max / sum of a value with its partner lane (lane ^ 32).
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): gives each XCD a contiguous range of tiles.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
