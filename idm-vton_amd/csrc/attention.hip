@@ -456,10 +456,12 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
     // tune = (rows64 << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
     // rows64 = 1: 64 query rows per wave (attn64_kernel).
-    const long rows = (long)p.B * p.heads * p.Nq;
-    int nw = 4, stg = 2;
-    if (rows / 128 < 512) nw = 2;
-    if (rows / 128 >= 2048) nw = 8;
+    // No tune: 8 waves (256 query rows per workgroup: fewest K/V re-reads) while that still gives most CUs a workgroup,
+    // else 4 waves with the 3-stage ring, 2 waves only for tiny problems (measured rule, profiles/r01_tune_report_*.json).
+    const long bh = (long)p.B * p.heads;
+    int nw = 4, stg = 3;
+    if (bh * ((p.Nq + 255) / 256) >= 200) { nw = 8; stg = 2; }
+    else if (bh * ((p.Nq + 127) / 128) < 64 && p.Nq <= 64) { nw = 2; stg = 2; }
     if (tune) { nw = tune & 0xff; stg = (tune >> 8) & 0xff; }
     if ((tune >> 16) & 0xff) {                           // 64-row waves (attn64_kernel): SELF mode, 4 waves, ring
         if (MODE != IDMVTON_ATTN_SELF || nw != 4 || (stg != 3 && stg != 4))

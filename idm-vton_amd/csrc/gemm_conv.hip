@@ -397,15 +397,20 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4;
     p.tiles_m = p.tiles_n = 0;
 
-    // Tile choice: tile_hint (variant<<28 | BN<<16 | BM) from the caller's tuning table, else the largest v0 tile that
-    // still gives >= 2 workgroups per CU (256 CUs); GEGLU needs 64-row wave tiles (BN=128).
-    int variant = 0, bn = 128, bm = 128;
+    // Tile choice: tile_hint (variant<<28 | BN<<16 | BM) from the caller's tuning table; GEGLU needs 64-row wave tiles (BN >= 128).
+    int variant = 1, bn = 64, bm = 64;
     if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0xffff; }
     else {
-        auto tiles = [&](int n_, int m_) { return (long)((a->N + n_ - 1) / n_) * ((a->M + m_ - 1) / m_); };
-        if (tiles(128, 128) >= 512) { bn = 128; bm = 128; }
-        else if (tiles(128, 64) >= 384 || geglu) { bn = 128; bm = 64; }
-        else { bn = 64; bm = 64; }
+        // No hint: the largest ring tile that still gives every CU a tile (measured rule, profiles/r01_tune_report_*.json:
+        // operand delivery per CU is the bound, so arithmetic intensity per tile wins until the grid no longer fills 256 CUs).
+        static const int cand[5][2] = {{256, 256}, {128, 256}, {128, 128}, {128, 64}, {64, 64}};
+        for (int i = 0; i < 5; ++i) {
+            const int n_ = cand[i][0], m_ = cand[i][1];
+            if (geglu && n_ < 128) continue;
+            if (a->vt && a->vt_n0 % n_ != 0) continue;
+            bn = n_; bm = m_;
+            if ((long)((a->N + n_ - 1) / n_) * ((a->M + m_ - 1) / m_) >= 200) break;
+        }
     }
     if (geglu) CHECK_ARG(bn >= 128, IDMVTON_E_ARG, "gemm_conv: GEGLU needs BN >= 128 (64-row wave tiles)");
     if (a->vt) CHECK_ARG(a->vt_n0 % bn == 0, IDMVTON_E_ARG, "gemm_conv: vt_n0 %% BN != 0");
