@@ -33,15 +33,17 @@ struct AttnParams {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int MODE, int NWAVES, int ST>
+template <typename T, int MODE, int NWAVES, int ST, int KT = 1>
 __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int QB = 32 * NWAVES;
     constexpr int IPW = 16 / NWAVES;                    // DMA instructions per wave per KV tile (8 K + 8 V^T in total)
+    constexpr int STAGE = KT * 16384;                   // KT 64-key tiles per LDS stage = per barrier (KT = 2: two-buffer loop only)
+    static_assert(KT == 1 || ST == 2, "multi-tile stages use the vmcnt(0) two-buffer loop");
     // [stage][K 8 KiB | V^T 8 KiB]; ring kernels add a per-wave 4 KiB Q tile (Q also arrives by LDS-DMA there: a plain
     // global load of Q before the loop makes hipcc re-wait for it -- vmcnt(0) -- inside every iteration, draining the ring)
-    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + (ST > 2 ? NWAVES * 4096 : 0)];
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE + (ST > 2 ? NWAVES * 4096 : 0)];
 
     const int lane = threadIdx.x & 63;
     const int wave = uniform(threadIdx.x >> 6);
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     } else {
         // Q tile of this wave: 32 rows x 128 B -> LDS (4 DMA instructions, same swizzle as K); read back after the first wait
         const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(p.q, p.qbytes);
-        char* dq = smem + ST * 16384 + wave * 4096;
+        char* dq = smem + ST * STAGE + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int R = i * 8 + (lane >> 3);
@@ -82,12 +84,12 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 
     // ---- loader ----
     const int lrow = lane >> 3, lslot = lane & 7;
-    auto issue = [&](int t, int buf) {
+    auto issue = [&](int t, char* tile) {
         const int sg = t < nt0 ? 0 : 1;
         const int kt = sg ? t - nt0 : t;
         const int nk = p.nk[sg];
         const int bsg = b - p.seg_b0[sg];
-        char* dst = smem + buf * 16384 + wave * (IPW * 1024);
+        char* dst = tile + wave * (IPW * 1024);
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
             const int j = wave * IPW + i;               // wave-uniform: 0..7 -> K rows, 8..15 -> V^T rows
@@ -130,32 +132,43 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
         if (nz > 0) { m_run = 0.f; l_run = u == 0 ? (float)nz : 0.f; }
     }
 
-    if constexpr (ST == 2) { if (nt > 0) issue(0, 0); }
+    const int ns = (nt + KT - 1) / KT;                    // stages
+    auto issue_stage = [&](int s, int bufi) {
+#pragma unroll
+        for (int sub = 0; sub < KT; ++sub)
+            if (s * KT + sub < nt) issue(s * KT + sub, smem + bufi * STAGE + sub * 16384);
+    };
+    if constexpr (ST == 2) { if (ns > 0) issue_stage(0, 0); }
     else {
 #pragma unroll
         for (int s = 0; s < ST - 1; ++s)
-            if (s < nt) issue(s, s);
+            if (s < ns) issue_stage(s, s);
         // Q (the oldest DMAs, issued by this wave for itself) has landed once at most the prologue tiles are outstanding
-        if (nt >= ST - 1) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();
-        const char* dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
+        if (ns >= ST - 1) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();
+        const char* dq = smem + ST * STAGE + wave * 4096 + l31 * 128;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(dq + (((2 * s + u) ^ ((l31 >> 1) & 7)) << 4));
     }
     int cbuf = 0, ibuf = ST - 1;
-    for (int t = 0; t < nt; ++t) {
+    for (int st_i = 0; st_i < ns; ++st_i) {
         if constexpr (ST == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+            if (st_i + 1 < ns) issue_stage(st_i + 1, (st_i + 1) & 1);
         } else {
-            if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * IPW>(); else wait_vmcnt<0>();
+            if (st_i + ST - 2 < ns) wait_vmcnt<(ST - 2) * IPW>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (t + ST - 1 < nt) issue(t + ST - 1, ibuf);
+            if (st_i + ST - 1 < ns) issue_stage(st_i + ST - 1, ibuf);
         }
-        const char* buf = smem + cbuf * 16384;
+        const char* sbuf = smem + cbuf * STAGE;
         cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
         ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
+#pragma unroll
+      for (int sub = 0; sub < KT; ++sub) {
+        const int t = st_i * KT + sub;
+        if (t >= nt) break;
+        const char* buf = sbuf + sub * 16384;
         const int sg = t < nt0 ? 0 : 1;
         const int kt = sg ? t - nt0 : t;
         const int valid = p.nk[sg] - kt * 64;            // keys of this tile that exist (>= 64: all)
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
                 m_run = NEG_BIG; l_run = 0.f;
             }
         }
+      }
     }
 
     // ---- finalise and store: lane holds O[q][h*64 + db*32 + 8g + 4u + j] ----
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
 template <typename T, int MODE>
 static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
-    // tune = (rows64 << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
+    // tune = (kt << 24) | (rows64 << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
     // rows64 = 1: 64 query rows per wave (attn64_kernel).
     // No tune: 8 waves (256 query rows per workgroup: fewest K/V re-reads) while that still gives most CUs a workgroup,
     // else 4 waves with the 3-stage ring, 2 waves only for tiny problems (measured rule, profiles/r01_tune_report_*.json).
@@ -476,6 +490,14 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     const int qbs = 32 * nw;
     p.nqb = (p.Nq + qbs - 1) / qbs;
     const dim3 grid(p.nqb * p.heads * p.B), block(nw * 64);
+    const int kt2 = (tune >> 24) & 0xf;                  // 2: two 64-key tiles per barrier (two-buffer loop, 4 or 8 waves)
+    if (kt2 == 2) {
+        if (stg != 2 || (nw != 4 && nw != 8)) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: 128-key stages need stages=2, waves 4|8");
+        if (nw == 4) hipLaunchKernelGGL((attn_kernel<T, MODE, 4, 2, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((attn_kernel<T, MODE, 8, 2, 2>), grid, block, 0, st, p);
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
 #define ATTN_CASE(NW_, ST_) if (nw == NW_ && stg == ST_) { hipLaunchKernelGGL((attn_kernel<T, MODE, NW_, ST_>), grid, block, 0, st, p); } else
     ATTN_CASE(2, 2) ATTN_CASE(4, 2) ATTN_CASE(8, 2)
     ATTN_CASE(2, 3) ATTN_CASE(4, 3) ATTN_CASE(8, 3)

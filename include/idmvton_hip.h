@@ -109,7 +109,7 @@ typedef struct {
     int32_t k_rows[2];           /* rows per batch element in k[s] (>= nk; 0 means nk)           */
     int32_t seg_b0[2];
     float ip_scale;
-    int32_t tune;                /* 0 = auto; else (rows64<<16)|(stages<<8)|waves: stages 2 (two-buffer) | 3 | 4 (LDS ring),
+    int32_t tune;                /* 0 = auto; else (kt<<24)|(rows64<<16)|(stages<<8)|waves (kt=2: two 64-key tiles per barrier, stages=2): stages 2 (two-buffer) | 3 | 4 (LDS ring),
                                     waves 2|4|8; rows64=1: 64 query rows per wave (SELF mode, 4 waves, ring) */
 } idmvton_attn_args;
 int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);

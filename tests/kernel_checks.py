@@ -333,6 +333,16 @@ def all_checks(dev="cuda"):
                 add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn))
                 add(f"attn_cross_77_16_N768_{tag}", lambda dt=dt, tn=tn: check_attn_cross(4, 4, 768, dt, dev, tune=tn))
                 add(f"attn_cross_scale0.5_N200_{tag}", lambda dt=dt, tn=tn: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5, tune=tn))
+        for nw in (4, 8):                                # two 64-key tiles per LDS stage / barrier
+            tn, tag = (2 << 24) | (2 << 8) | nw, f"k2w{nw}"
+            add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
+            add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn))
+            add(f"attn_self_odd_tiles_N320_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 320, dt, dev, n_garm=192, b0=1, tune=tn))
+            add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
+            add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn))
+            add(f"attn_self_N3072_h10_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=tn))
+            add(f"attn_cross_77_16_N768_{tag}", lambda dt=dt, tn=tn: check_attn_cross(4, 4, 768, dt, dev, tune=tn))
+            add(f"attn_cross_scale0.5_N200_{tag}", lambda dt=dt, tn=tn: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5, tune=tn))
         for stg in (3, 4):                               # 64 query rows per wave (attn64_kernel)
             tn, tag = (1 << 16) | (stg << 8) | 4, f"r64s{stg}"
             add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))

@@ -3,7 +3,7 @@ cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo BUILD FAILED; tail -20 $O/build.log; exit 1; }
-timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=line -p no:cacheprovider -k "r64s" > $O/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_new.log
+timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=line -p no:cacheprovider -k "k2w or auto or attn" > $O/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_new.log
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kp0 -o kp -- python $R/tools/gpu_kprobe.py 5 > $O/kp0.log 2>&1; echo "kp0 rc=$?"
 cd $R

@@ -44,7 +44,7 @@ def main():
         kg, vg = r(B // 2, N, C), r(B // 2, C, N)
         out = torch.empty(B, N, C, dtype=dt, device=dev)
         segs = [dict(k=k, vt=v, nk=N, ldk=C, ldvt=N), dict(k=kg, vt=vg, nk=N, ldk=C, ldvt=N, b0=B // 2)]
-        for tn in ((2 << 8) | 8, (3 << 8) | 4, (2 << 8) | 4, (1 << 16) | (3 << 8) | 4, (1 << 16) | (4 << 8) | 4):
+        for tn in ((2 << 8) | 8, (3 << 8) | 4, (2 << 24) | (2 << 8) | 8, (2 << 24) | (2 << 8) | 4):
             jobs.append(lambda tn=tn, q=q, out=out, segs=segs, hd=hd: ops.attention(q, out, segs, hd, tune=tn))
     for j in jobs:
         for _ in range(reps):

@@ -25,7 +25,8 @@ GEMM_CANDS = [("v0_128x128", hint(0, 128, 128)), ("v0_128x64", hint(0, 128, 64))
               ("r_256x256", hint(1, 256, 256)), ("r_128x256", hint(1, 128, 256)), ("r_128x128", hint(1, 128, 128)), ("r_128x64", hint(1, 128, 64)),
               ("r_64x64", hint(1, 64, 64))]
 ATTN_CANDS = [(f"w{nw}s{st}", (st << 8) | nw) for nw in (2, 4, 8) for st in (2, 3, 4)] + \
-             [(f"r64s{st}", (1 << 16) | (st << 8) | 4) for st in (3, 4)]
+             [(f"r64s{st}", (1 << 16) | (st << 8) | 4) for st in (3, 4)] + \
+             [(f"k2w{nw}", (2 << 24) | (2 << 8) | nw) for nw in (4, 8)]
 
 
 def main():
