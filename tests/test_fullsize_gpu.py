@@ -97,3 +97,21 @@ def test_execution_modes_bit_identical_at_full_size(full):
         outs.append(engine.denoise(st, **kw).clone())
     assert torch.isfinite(outs[0]).all()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@torch.no_grad()
+def test_config4_highres_shapes(full):
+    """BASELINE.json configs[3]: 1024x1536 (W x H; latent 192x128 -> 6144 / 1536 tokens), B=1.  One denoising step through both
+    execution modes: finite, bit-identical between modes and run to run (long-sequence attention: 6144 + 6144 keys)."""
+    import bench
+    engine, dev = full
+    inp = bench.synth_inputs(1, 1536, 1024, 2, dev, 0)
+    outs = []
+    for kw in (dict(), dict(overlap=True), dict()):
+        st = engine.prepare(num_inference_steps=2, guidance_scale=2.0, scheduler="ddim", **inp)
+        assert (st["h"], st["w"]) == (192, 128)
+        outs.append(engine.denoise(st, **kw).clone())
+    assert torch.isfinite(outs[0]).all() and outs[0].shape == (1, 4, 192, 128)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    img = engine.decode(outs[0])
+    assert img.shape == (1, 3, 1536, 1024) and torch.isfinite(img).all() and 0.0 <= img.min().item() and img.max().item() <= 1.0
