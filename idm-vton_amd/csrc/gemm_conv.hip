@@ -114,6 +114,40 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     };
 
+    // The same tile issued in four parts (DMA instructions j = s, s+4, ... in part s; j < WI: weight rows, else activation
+    // rows), one part in front of each 16-deep k-step's MFMAs: measured on MI355X (tools/gpu_bw_probe.py) one CU pulls
+    // 50-60 B/clk from L2 by LDS-DMA when the requests are spread out, but a burst of 6-8 KiB-sized DMA instructions per
+    // wave right after the barrier costs ~150 cycles of issue each with the matrix pipe idle.
+    idmvton_seg sgc = p.seg[0];
+    __amdgpu_buffer_rsrc_t rs_xc = rs_x0;
+    auto issue_part = [&](int t, int buf, int s) {
+        constexpr int LPT_ = WI + XI;
+        char* dW = sW + buf * WBYTES + wave * (WI * 1024);
+        char* dX = sX + buf * XBYTES + wave * (XI * 1024);
+        if constexpr (!LIN) {
+            if (s == 0) { sgc = p.seg[si]; rs_xc = make_rsrc(sgc.ptr, sgc.bytes); }
+        }
+#pragma unroll
+        for (int j = 0; j < LPT_; ++j) {
+            if ((j & 3) != s) continue;
+            if (j < WI) dma16(rs_w, dW + j * 1024, w_off[j] + (uint32_t)t * 128u);
+            else {
+                const int i = j - WI;
+                if constexpr (LIN) dma16(rs_x0, dX + i * 1024, x_off[i] + (uint32_t)t * 128u);
+                else {
+                    int iy = x_oy[i] + sgc.dy, ix = x_ox[i] + sgc.dx;
+                    const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    const uint32_t off = ((uint32_t)(x_pix[i] + iy * p.Wi + ix) * (uint32_t)sgc.pitch + sgc.coff + kseg + x_c8[i]) * 2u;
+                    dma16(rs_xc, dX + i * 1024, ok ? off : OOB_SENTINEL);
+                }
+            }
+        }
+        if constexpr (!LIN) {
+            if (s == 3) { kseg += 64; if (kseg >= sgc.len) { kseg = 0; ++si; } }
+        }
+    };
+
     // ---- fragment read addresses (row*128 and the row's swizzle key) ----
     int a_row[NI], a_swz[NI], b_row[MI], b_swz[MI];
 #pragma unroll
@@ -131,7 +165,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 
     auto frag_a = [&](const char* bW, int s, int ni) { return *(const v8*)(bW + a_row[ni] + (((2 * s + u) ^ a_swz[ni]) << 4)); };
     auto frag_b = [&](const char* bX, int s, int mi) { return *(const v8*)(bX + b_row[mi] + (((2 * s + u) ^ b_swz[mi]) << 4)); };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, bool spread = false, int t_next = 0, int buf_next = 0) {
         const char* bW = sW + buf * WBYTES;
         const char* bX = sX + buf * XBYTES;
         if constexpr (!PF) {
@@ -142,6 +176,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
                 for (int ni = 0; ni < NI; ++ni) a[ni] = frag_a(bW, s, ni);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) b[mi] = frag_b(bX, s, mi);
+                if constexpr (V1) {
+                    if (spread) issue_part(t_next, buf_next, s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -164,6 +202,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) b[(s + 1) & 1][mi] = frag_b(bX, s + 1, mi);
                 }
+                if (spread) issue_part(t_next, buf_next, s);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
@@ -197,8 +236,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
             if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * LPT>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                // every wave's share of tile t landed; all are done with tile t-1
             asm volatile("" ::: "memory");
-            if (t + ST - 1 < nt) issue(t + ST - 1, ibuf);
-            compute(cbuf);
+            compute(cbuf, t + ST - 1 < nt, t + ST - 1, ibuf);    // tile t+ST-1's DMA is issued in four parts between the k-steps
             cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
             ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
         }
