@@ -215,29 +215,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     };
 
-    // L2 touch (LIN ring kernels): one 4-byte-per-lane LDS-DMA per wave reads one dword of each of the tile's BN + BM
-    // 128-byte operand lines, LEAD iterations before the tile's real DMA is issued.  Every K step of a tile contains lines
-    // this XCD has never touched (18 % L2 misses measured): without the touch each step waits a full HBM round trip
-    // (~2 us under load, more than the 1-2 tiles of LDS prefetch can cover); with it the real DMA finds its lines in L2.
-    // Always issued (out-of-range tiles read the buffer descriptor's zero) so the counted vmcnt stays uniform.
-    constexpr int PFI = (V1 && LIN) ? 1 : 0;
-    constexpr int LEAD = 3;
-    const uint32_t tch_off = [&]() -> uint32_t {
-        const int R = wave * 64 + lane;                  // line R of [BN weight rows | BM activation rows]
-        if (R < BN) return ((uint32_t)(n0 + R) * (uint32_t)p.Ktot) * 2u;
-        const int m = m0 + R - BN;
-        return (R < BN + BM && m < p.M) ? ((uint32_t)m * (uint32_t)p.seg[0].pitch + p.seg[0].coff) * 2u : OOB_SENTINEL;
-    }();
-    const bool tch_w = wave * 64 < BN;                    // wave-uniform (BN is a multiple of 64): scalar branch, one DMA per wave
-    auto touch = [&](int t) {
-        if constexpr (PFI) {
-            char* sink = smem + ST * (WBYTES + XBYTES) + wave * 256;
-            const uint32_t off = (t < (p.Ktot >> 6)) ? tch_off + (uint32_t)t * 128u : OOB_SENTINEL;
-            if (tch_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sink), 4, off, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, LDS_PTR(sink), 4, off, 0, 0, 0);
-        }
-    };
-
     const int nt = p.Ktot >> 6;
     if constexpr (!V1) {
         issue(0, 0);
@@ -249,23 +226,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     } else {
         constexpr int LPT = WI + XI;                     // DMA instructions per wave per tile
-        // outstanding ops allowed while waiting for tile t: the (ST-2) younger tiles with their touches + the touch issued
-        // after tile t's own DMA (issue order per iteration: real DMA parts, then the touch)
-        constexpr int NWAIT = (ST - 2) * (LPT + PFI) + PFI;
-        static_assert(NWAIT < 64 && ST <= LEAD + 1, "vmcnt immediate is 6 bits; prologue counts assume ST-1 <= LEAD");
+        static_assert((ST - 2) * LPT < 64, "vmcnt immediate is 6 bits");
 #pragma unroll
         for (int s = 0; s < ST - 1; ++s)
             if (s < nt) issue(s, s);
-#pragma unroll
-        for (int s = 0; s < LEAD; ++s) touch(ST - 1 + s);
         int cbuf = 0, ibuf = ST - 1;                     // buffer computed this iteration / buffer refilled this iteration
         for (int t = 0; t < nt; ++t) {
             // tiles t .. t+ST-2 are outstanding (fewer at the tail); only tile t has to have landed
-            if (t + ST - 2 < nt) wait_vmcnt<NWAIT>(); else wait_vmcnt<0>();
+            if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * LPT>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                // every wave's share of tile t landed; all are done with tile t-1
             asm volatile("" ::: "memory");
             compute(cbuf, t + ST - 1 < nt, t + ST - 1, ibuf);    // tile t+ST-1's DMA is issued in four parts between the k-steps
-            touch(t + ST - 1 + LEAD);
             cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
             ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
         }
@@ -369,7 +340,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 //                       128x64 4 waves ST=3 (72 KiB, 2 blocks/CU), 64x64 4 waves ST=4 (64 KiB, 2 blocks/CU)
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC>
 __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128 + (V1 && LIN ? WN * WM * 256 : 0)];   // + L2-touch sink
+    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tm, tn;
     if constexpr (!V1) { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
