@@ -338,7 +338,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 //   v1 (ring)         : 256x256 8 waves ST=2 (128 KiB, 32 B/clk/CU of operand traffic at MFMA peak),
 //                       128x256 8 waves ST=3 (144 KiB, 1 block/CU), 128x128 4 waves ST=3 (96 KiB),
 //                       128x64 4 waves ST=3 (72 KiB, 2 blocks/CU), 64x64 4 waves ST=4 (64 KiB, 2 blocks/CU)
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC>
+//   v2                : the v1 tiles (except 128x128, which already has it) with the fragments of k-step s+1 read from LDS
+//                       ahead of the MFMAs of step s (PMC: 45 % of wave cycles of the 8-wave tiles sit in s_waitcnt, mostly
+//                       lgkmcnt in front of each k-step; both waves of a SIMD are barrier-aligned so neither covers the other)
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC, bool PFX = false>
 __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
@@ -355,17 +358,17 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
         tn = rem / gsz; tm = first + (rem - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1, true>(p, smem, m0, n0);   // block-uniform
-    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1, false>(p, smem, m0, n0);
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true>(p, smem, m0, n0);   // block-uniform
+    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false>(p, smem, m0, n0);
 }
 
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
 static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
     if constexpr (V1) {                                  // the v0 kernels keep the one general loader
-        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, true, OCC>), grid, block, 0, st, p); return; }
+        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, true, OCC, PFX>), grid, block, 0, st, p); return; }
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC, PFX>), grid, block, 0, st, p);
 }
 
 template <typename T>
@@ -385,6 +388,12 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, true, 2>(p, lin, st);
         else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, true, 2>(p, lin, st);
         else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v1 tile %dx%d", bn, bm);
+    } else if (variant == 2) {                           // ring tiles with the register-prefetched fragment pipeline on every tile
+        if (bn == 256 && bm == 256) launch_cfg<T, 256, 256, 2, 4, 2, true, 2, true>(p, lin, st);
+        else if (bn == 128 && bm == 256) launch_cfg<T, 128, 256, 2, 4, 3, true, 2, true>(p, lin, st);
+        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, true, 2, true>(p, lin, st);
+        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, true, 2, true>(p, lin, st);
+        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v2 tile %dx%d", bn, bm);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;

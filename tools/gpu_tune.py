@@ -22,6 +22,7 @@ def hint(variant, bn, bm):
 
 
 GEMM_CANDS = [("v0_128x128", hint(0, 128, 128)), ("v0_128x64", hint(0, 128, 64)), ("v0_64x64", hint(0, 64, 64)),
+              ("p_256x256", hint(2, 256, 256)), ("p_128x256", hint(2, 128, 256)), ("p_128x64", hint(2, 128, 64)), ("p_64x64", hint(2, 64, 64)),
               ("r_256x256", hint(1, 256, 256)), ("r_128x256", hint(1, 128, 256)), ("r_128x128", hint(1, 128, 128)), ("r_128x64", hint(1, 128, 64)),
               ("r_64x64", hint(1, 64, 64))]
 ATTN_CANDS = [(f"w{nw}s{st}", (st << 8) | nw) for nw in (2, 4, 8) for st in (2, 3, 4)] + \
@@ -41,7 +42,7 @@ def main():
     args = ap.parse_args()
     import bench
     from idm_vton_amd import ffi, ops
-    gemm_cands = [c for c in GEMM_CANDS if not (args.skip_ring and c[0].startswith("r_"))]
+    gemm_cands = [c for c in GEMM_CANDS if not (args.skip_ring and c[0][:2] in ("r_", "p_"))]
     attn_cands = [] if args.skip_attn_variants else ATTN_CANDS
     ops.load_tune(None)                                  # tune from the built-in heuristics, not from a previous table
     dev, dt = torch.device("cuda", 0), torch.bfloat16
