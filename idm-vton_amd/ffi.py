@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidmvton_hip.so")
+LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_hip.so")   # override: A/B of library builds
 
 F16, BF16, F32 = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
