@@ -11,7 +11,7 @@ Everything from the VAE encodes to the VAE decode runs on the HIP kernels throug
 3 VAE encodes, Resampler, hoisted K/V + embedding tables, the denoising loop (GarmentNet || TryonNet on two streams,
 hipGraph replay) and the decode.  RNG draws follow the reference's order with the caller's generator.
 
-Loud differences: guidance_scale <= 1 (no CFG), `padding_mask_crop`, `masked_image_latents=`, `timesteps=`,
+Loud differences: guidance_scale <= 1 (no CFG), strength != 1.0, `padding_mask_crop`, `masked_image_latents=`, `timesteps=`,
 `denoising_start/end`, `guidance_rescale`, `cross_attention_kwargs`, step callbacks, `num_images_per_prompt != 1` and
 schedulers other than DDPM/DDIM raise NotImplementedError: the reference scripts use none of them.
 """
@@ -301,8 +301,11 @@ class StableDiffusionXLInpaintPipeline:
         self._guidance_scale = guidance_scale
         if not self.do_classifier_free_guidance:
             raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance): the HIP engine batches the two CFG halves")
-        if int(num_inference_steps * min(strength, 1.0)) < num_inference_steps and strength < 0.999:
-            raise NotImplementedError(f"strength={strength}: only full-strength inpainting (strength ~ 1.0: inference.py:404) is supported")
+        if strength != 1.0:
+            # reference :1561-1567,1610-1630: strength < 1 starts from the noised image latents and skips the first
+            # int(n*(1-strength)) steps (the signature default 0.9999 already drops one); only the strength = 1.0 path that
+            # inference.py:404 and gradio_demo/app.py:225 take (pure-noise start, all n steps) is implemented
+            raise NotImplementedError(f"strength={strength}: only strength=1.0 (the value the try-on scripts pass) is supported")
         kind = {DDPMScheduler: "ddpm", DDIMScheduler: "ddim"}.get(type(self.scheduler))
         if kind is None:
             kind = {"DDPMScheduler": "ddpm", "DDIMScheduler": "ddim"}.get(type(self.scheduler).__name__)

@@ -117,3 +117,27 @@ def test_world_size_2_gloo_broadcast_and_sharding(tmp_path):
     assert rows[0][2] == rows[1][2] and float(rows[0][2]) != 0.0          # both ranks hold rank 0's weights
     assert (rows[0][3], rows[0][4], rows[1][3], rows[1][4]) == ("0", "3", "3", "5")   # disjoint contiguous image shards
     assert rows[0][5] == rows[1][5] == "2.0"                               # max over ranks
+
+
+def test_tuning_table_entries_decode_to_supported_kernel_configurations():
+    """idm-vton_amd/tune_gfx950.json (measured on the MI355X by tools/gpu_tune.py) may only name configurations the
+    library instantiates: a stale table must fail here, not at the first launch of a pipeline call."""
+    import json
+    from idm_vton_amd import ops
+    t = json.load(open(ops.TUNE_PATH))
+    gemm_ok = {0: {(128, 128), (128, 64), (64, 64)},
+               1: {(256, 256), (128, 256), (128, 128), (128, 64), (64, 64)},
+               2: {(256, 256), (128, 256), (128, 64), (64, 64)}}
+    assert t["gemm"] and t["attn"]
+    for key, h in t["gemm"].items():
+        f = [int(x) for x in key.split(",")]
+        assert len(f) == 10 and f[0] in (0, 1)                                   # dtype,M,N,K,nseg,Wo,stride,ups,mode,vt
+        variant, bn, bm = (h >> 28) & 0xf, (h >> 16) & 0xfff, h & 0xffff
+        assert (bn, bm) in gemm_ok.get(variant, ()), (key, h)
+        if f[8] == 1:
+            assert bn >= 128, (key, "GEGLU needs 64-row wave tiles")
+    for key, v in t["attn"].items():
+        assert len(key.split(",")) == 9
+        kt, rows64, st, nw = (v >> 24) & 0xf, (v >> 16) & 0xff, (v >> 8) & 0xff, v & 0xff
+        assert nw in (2, 4, 8) and st in (2, 3, 4) and kt in (0, 2) and rows64 in (0, 1), (key, v)
+        assert not (kt == 2 and (st != 2 or nw == 2)) and not (rows64 and (nw != 4 or st == 2)), (key, v)
