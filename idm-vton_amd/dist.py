@@ -75,3 +75,9 @@ def max_over_ranks(value, device):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown():
+    """Tear the process group down (every rank, after its last collective)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
