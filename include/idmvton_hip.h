@@ -75,7 +75,8 @@ typedef struct {
     void* vt; int32_t vt_n0; int32_t vt_tokens;
     int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
-                                    variant 1 with register-prefetched fragments on every tile.
+                                    variant 1 with register-prefetched fragments on every tile; variant 3 (experimental) =
+                                    variant 1 with the K walk rotated per tile (plain Linear launches only).
                                     Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
