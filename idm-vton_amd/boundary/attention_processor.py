@@ -64,9 +64,9 @@ class _WeightCat:
 
 def _project_kv(enc, w_kv, b_kv, inner):
     """enc [B][L][Ck] -> (K [B*L8][inner], V^T [B][inner][L8], L8): one GEMM, K rows / V^T epilogues; token rows padded
-    with zeros to a multiple of 8 (V^T rows must be 16-byte aligned; padded keys are masked by nk)."""
+    with zeros to a multiple of 16 (the V^T epilogue writes the attention kernel's key order; padded keys are masked by nk)."""
     B, L, Ck = enc.shape
-    L8 = (L + 7) // 8 * 8
+    L8 = ops.round16(L)
     if L8 != L:
         pad = torch.zeros(B, L8, Ck, dtype=enc.dtype, device=enc.device)
         pad[:, :L] = enc
@@ -112,7 +112,7 @@ class AttnProcessor2_0(nn.Module):
         if encoder_hidden_states is None:
             # self-attention: one fused QKV GEMM (q|k row-major, V^T epilogue); keys == queries (:240-246)
             w, b = self._qkv.get([attn.to_q, attn.to_k, attn.to_v])
-            if L % 8 == 0:
+            if L % 16 == 0:
                 qk = torch.empty(B * L, 2 * inner, dtype=dt, device=dev)
                 vt = torch.empty(B, inner, L, dtype=dt, device=dev)
                 ops.linear(x.reshape(B * L, C), w, bias=b, out=qk, vt=vt, vt_n0=2 * inner, vt_tokens=L)

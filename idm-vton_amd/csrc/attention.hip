@@ -4,9 +4,11 @@
 // hold different keys of that row).  Row max / row sum / the O rescale are then lane-local (one cross-half exchange per
 // tile for the max), and P goes from the S^T accumulator straight into the PV MFMA "B" operand with no shuffle: the
 // key <-> k-slot assignment of the PV contraction is chosen to be exactly the one the QK^T accumulator already has
-// (slot jj of half-wave u  <->  key 16*step + (jj&3) + 8*(jj>>2) + 4u), and the V^T fragment reads use the same map.
-// V arrives already transposed ([channel][key], written by the projection GEMM's vt epilogue), so K tiles ([key][64 d])
-// and V^T tiles ([64 d][key]) are both 64 rows x 128 B and share one LDS-DMA loader and one XOR swizzle
+// (slot jj of half-wave u  <->  key 16*step + (jj&3) + 8*(jj>>2) + 4u).  V arrives already transposed AND in that key order
+// ([channel][position], position = key with bits 2 and 3 swapped inside each group of 16; written by the projection GEMM's
+// vt epilogue with vt_perm = 1), so the 8 keys of a half-wave's k-slots are one 16-byte ds_read_b128 and K tiles ([key][64 d])
+// and V^T tiles ([64 d][64 positions]) are both 64 rows x 128 B and share one LDS-DMA loader, one XOR swizzle and one
+// conflict-free read pattern
 // (row r, 16-byte chunk c stored at r*128 + ((c ^ ((r>>1)&7))<<4); swizzle applied on the DMA source address).
 // Key segments: SELF mode walks up to two segments under one softmax (own tokens, garment tokens); a segment that is
 // absent for this batch element (CFG-unconditional half: all-zero garment features) contributes nk keys with logit 0 and
@@ -27,20 +29,21 @@ struct AttnParams {
     int nk[2]; int krows[2]; int seg_b0[2];
     float ip_scale;
     int nqb;
+    int pp_flags; float pp_thr;
 };
 
 #define NEG_BIG (-1.0e30f)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int MODE, int NWAVES, int ST, int KT = 1>
+template <typename T, int MODE, int NWAVES, int ST>
 __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int QB = 32 * NWAVES;
     constexpr int IPW = 16 / NWAVES;                    // DMA instructions per wave per KV tile (8 K + 8 V^T in total)
-    constexpr int STAGE = KT * 16384;                   // KT 64-key tiles per LDS stage = per barrier (KT = 2: two-buffer loop only)
-    static_assert(KT == 1 || ST == 2, "multi-tile stages use the vmcnt(0) two-buffer loop");
+    constexpr int STAGE = 16384;                        // one 64-key tile per LDS stage = per barrier
+    constexpr int KT = 1;
     // [stage][K 8 KiB | V^T 8 KiB]; ring kernels add a per-wave 4 KiB Q tile (Q also arrives by LDS-DMA there: a plain
     // global load of Q before the loop makes hipcc re-wait for it -- vmcnt(0) -- inside every iteration, draining the ring)
     __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE + (ST > 2 ? NWAVES * 4096 : 0)];
@@ -100,9 +103,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
                 const uint32_t off = (uint32_t)((((size_t)bsg * p.krows[sg] + key) * p.ldk[sg] + h * 64 + c * 8) * 2);
                 dma16(make_rsrc(p.k[sg], p.kbytes[sg]), dst + i * 1024, key < nk ? off : OOB_SENTINEL);
             } else {
-                const int key0 = kt * 64 + c * 8;
-                const uint32_t off = (uint32_t)((((size_t)bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + key0) * 2);
-                dma16(make_rsrc(p.vt[sg], p.vtbytes[sg]), dst + i * 1024, key0 < nk ? off : OOB_SENTINEL);
+                // chunk c of V^T row R holds tile positions [8c, 8c+8) = keys 16(c>>1) + 4(c&1) + {0..3, 8..11} (key order)
+                const int kmin = kt * 64 + 16 * (c >> 1) + 4 * (c & 1);
+                const uint32_t off = (uint32_t)((((size_t)bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + kt * 64 + c * 8) * 2);
+                dma16(make_rsrc(p.vt[sg], p.vtbytes[sg]), dst + i * 1024, kmin < nk ? off : OOB_SENTINEL);
             }
         }
     };
@@ -112,10 +116,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     int k_addr[2], k_swz[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; k_addr[kb] = r * 128; k_swz[kb] = (r >> 1) & 7; }
-    // V^T (A operand of O^T): row = d db*32 + l31; for PV step ks: chunks 2ks and 2ks+1, byte u*8 inside each
+    // V^T (A operand of O^T): row = d db*32 + l31; PV step ks, half-wave u: chunk 2ks + u (V^T is stored in key order, so the
+    // 8 keys 16ks + {0..3, 8..11} + 4u this half contracts are one 16-byte read: same conflict-free pattern as K)
     int v_addr[2], v_swz[2];
 #pragma unroll
-    for (int db = 0; db < 2; ++db) { const int r = db * 32 + l31; v_addr[db] = 8192 + r * 128 + u * 8; v_swz[db] = (r >> 1) & 7; }
+    for (int db = 0; db < 2; ++db) { const int r = db * 32 + l31; v_addr[db] = 8192 + r * 128; v_swz[db] = (r >> 1) & 7; }
 
     const float cs = 0.125f * 1.44269504088896341f;      // softmax scale (d^-0.5) folded with log2(e)
     f32x16 oacc[2], ofin[2];
@@ -228,11 +233,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const v4 lo = *(const v4*)(buf + v_addr[db] + (((2 * ks) ^ v_swz[db]) << 4));
-                const v4 hi = *(const v4*)(buf + v_addr[db] + (((2 * ks + 1) ^ v_swz[db]) << 4));
-                v8 vf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                const v8 vf = *(const v8*)(buf + v_addr[db] + (((2 * ks + u) ^ v_swz[db]) << 4));
                 oacc[db] = VT<T>::mfma(vf, pf[ks], oacc[db]);
             }
         if (MODE == IDMVTON_ATTN_CROSS) {
@@ -268,32 +269,51 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// attn64_kernel: SELF mode, 4 waves x 64 query rows (two 32-row q-blocks per wave), LDS ring.  Every K fragment read from LDS
-// feeds two MFMAs (one per q-block), and the two q-blocks' chains are independent: while one block's online softmax runs on
-// the VALU, the other block's QK^T / PV MFMAs keep the matrix pipe busy from the same wave (1 wave per SIMD per workgroup).
-template <typename T, int ST>
-__global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
+// attn_pp_kernel: SELF mode, 8 waves x 32 query rows, the two waves of every SIMD in PING-PONG.
+//
+// With head_dim 64 a 64-key tile costs a wave 16 MFMAs (512 matrix-pipe cycles) and ~170 VALU/transcendental instructions of
+// online softmax -- about the same time.  A wave cannot overlap the two by itself (the softmax consumes the QK^T accumulator
+// and produces the PV operand), and two waves that run the same code in lock-step after one barrier per tile (attn_kernel)
+// collide on the matrix pipe and then on the VALU.  Here the per-tile work is cut into two barrier-delimited blocks,
+//     MFMA block j : O^T += V^T(j-1) . P^T(j-1)   and   S^T(j) = K(j) . Q^T        (16 MFMA on 4 independent accumulators)
+//     VALU block j : online softmax of S^T(j) -> P^T(j)                            (no LDS, no matrix pipe)
+// and the two wave groups (the waves w and w+4 share a SIMD) run them one block apart: while group 0 is in MFMA block j,
+// group 1 is in VALU block j-1, then they swap.  Every phase starts with one workgroup s_barrier, both groups execute the
+// same number of barriers (2 per tile + 2).
+// LDS stage s = { K tile s | V^T tile s-1 } (16 KiB): exactly what MFMA block s reads (group 0 in phase 2s, group 1 in phase
+// 2s+1), filled by LDS-DMA ST-1 stages ahead by all 8 waves (2 instructions each), counted vmcnt across the raw barriers.
+// Rescale: the running max is only moved (and O, l rescaled) when some row's max grew by more than `thr` (log2 units); rows
+// keep exponentiating against the older max otherwise (P <= 2^thr, exact in the final normalisation because l carries the same
+// scale).  The decision for tile j is taken in VALU block j, after PV(j-1) has completed and before P(j) is exponentiated.
+// DEEP = 1: one workgroup per CU (up to 256 VGPRs): every MFMA block reads its 16 fragments from LDS up front (one exposed LDS
+// latency per block); DEEP = 0: 128 VGPRs, two workgroups per CU, fragments read two MFMAs ahead (the other workgroup's waves
+// fill the gaps).
+template <typename T, int ST, bool PRIO, bool DEEP>
+__global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnParams p) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
-    constexpr int NW = 4, QB = 256, IPW = 4;
-    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + NW * 8192];   // [stage][K | V^T] + per-wave Q (64 rows)
+    constexpr int NW = 8, QB = 256, IPW = 2;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + NW * 4096];   // [stage][K | V^T] + per-wave Q tile
 
     const int lane = threadIdx.x & 63;
     const int wave = uniform(threadIdx.x >> 6);
     const int u = lane >> 5, l31 = lane & 31;
+    const int grp = (p.pp_flags & 1) ? (wave & 1) : (wave >> 2);      // wave-uniform
+    const float thr = p.pp_thr;
+
     const int wg = xcd_remap(blockIdx.x, p.nqb * p.heads * p.B);
     const int bh = wg / p.nqb, qb = wg - bh * p.nqb;
     const int b = bh / p.heads, h = bh - b * p.heads;
-    const int row0 = qb * QB + wave * 64;
+    const int q_row = qb * QB + wave * 32 + l31;
 
-    {   // Q tile of this wave: 64 rows x 128 B -> LDS (8 DMA instructions, K's swizzle)
+    {   // Q tile of this wave: 32 rows x 128 B -> LDS (4 DMA instructions, K's swizzle)
         const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(p.q, p.qbytes);
-        char* dq = smem + ST * 16384 + wave * 8192;
+        char* dq = smem + ST * 16384 + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int R = i * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((R >> 1) & 7);
-            int row = row0 + R;
+            int row = qb * QB + wave * 32 + R;
             row = row < p.Nq ? row : p.Nq - 1;
             dma16(rs_q, dq + i * 1024, (uint32_t)((((size_t)b * p.Nq + row) * p.ldq + h * 64 + c * 8) * 2));
         }
@@ -304,172 +324,216 @@ __global__ __launch_bounds__(256) void attn64_kernel(const AttnParams p) {
     const int nt1 = pres1 ? (p.nk[1] + 63) >> 6 : 0;
     const int nt = nt0 + nt1;
 
+    // ---- loader: stage s = K(s) (DMA instructions j = 0..7: waves 0-3) | V^T(s-1) (j = 8..15: waves 4-7).  A wave loads
+    // either K rows or V^T rows for the whole kernel, so everything that depends on that choice is folded into per-lane
+    // constants here and the in-loop issue is branch-free: offset = rowbase[seg][i] + kt * tstep[seg]; a chunk is fetched iff
+    // its smallest key index lim[i] + 64 kt exists (< nk[seg]); everything else (tiles -1 and nt, key tails) reads zeros.
     const int lrow = lane >> 3, lslot = lane & 7;
-    auto issue = [&](int t, int buf) {
-        const int sg = t < nt0 ? 0 : 1;
-        const int kt = sg ? t - nt0 : t;
-        const int nk = p.nk[sg];
-        const int bsg = b - p.seg_b0[sg];
-        char* dst = smem + buf * 16384 + wave * (IPW * 1024);
+    const bool is_k = wave < 4;
+    const int t_shift = is_k ? 0 : 1;                    // this wave's tile of stage s is s - t_shift
+    uint32_t rowbase[2][IPW], tstep[2];
+    int lim[IPW];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        const size_t bsg = (size_t)(b - p.seg_b0[sg] > 0 ? b - p.seg_b0[sg] : 0);
+        tstep[sg] = is_k ? (uint32_t)(64 * p.ldk[sg] * 2) : 128u;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
-            const int j = wave * IPW + i;               // wave-uniform: 0..7 -> K rows, 8..15 -> V^T rows
-            const int R = (j & 7) * 8 + lrow;
+            const int R = ((wave * IPW + i) & 7) * 8 + lrow;
             const int c = lslot ^ ((R >> 1) & 7);
-            if (j < 8) {
-                const int key = kt * 64 + R;
-                const uint32_t off = (uint32_t)((((size_t)bsg * p.krows[sg] + key) * p.ldk[sg] + h * 64 + c * 8) * 2);
-                dma16(make_rsrc(p.k[sg], p.kbytes[sg]), dst + i * 1024, key < nk ? off : OOB_SENTINEL);
-            } else {
-                const int key0 = kt * 64 + c * 8;
-                const uint32_t off = (uint32_t)((((size_t)bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + key0) * 2);
-                dma16(make_rsrc(p.vt[sg], p.vtbytes[sg]), dst + i * 1024, key0 < nk ? off : OOB_SENTINEL);
-            }
+            rowbase[sg][i] = is_k ? (uint32_t)(((bsg * p.krows[sg] + R) * p.ldk[sg] + h * 64 + c * 8) * 2)
+                                  : (uint32_t)(((bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + c * 8) * 2);
+            // V^T chunk c holds tile positions [8c, 8c+8) = keys 16(c>>1) + 4(c&1) + {0..3, 8..11} (key order)
+            lim[i] = is_k ? R : 16 * (c >> 1) + 4 * (c & 1);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs0 = is_k ? make_rsrc(p.k[0], p.kbytes[0]) : make_rsrc(p.vt[0], p.vtbytes[0]);
+    const __amdgpu_buffer_rsrc_t rs1 = is_k ? make_rsrc(p.k[1], p.kbytes[1]) : make_rsrc(p.vt[1], p.vtbytes[1]);
+    auto issue_stage = [&](int s, int bufi) {
+        char* dst = smem + bufi * 16384 + wave * (IPW * 1024);
+        const int t = s - t_shift;
+        const bool in_range = t >= 0 && t < nt;
+        const bool sg1 = t >= nt0;
+        const int kt = sg1 ? t - nt0 : t;
+        const int room = in_range ? (sg1 ? p.nk[1] : p.nk[0]) - kt * 64 : 0;       // keys of this tile that exist
+        const uint32_t toff = (uint32_t)kt * (sg1 ? tstep[1] : tstep[0]);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const uint32_t off = (sg1 ? rowbase[1][i] : rowbase[0][i]) + toff;
+            if (sg1) dma16(rs1, dst + i * 1024, lim[i] < room ? off : OOB_SENTINEL);
+            else dma16(rs0, dst + i * 1024, lim[i] < room ? off : OOB_SENTINEL);
         }
     };
 
-    int k_addr[2], k_swz[2], v_addr[2], v_swz[2];
+    // ---- fragment addresses (row * 128 and the row's swizzle key); K rows = keys, V^T rows = d ----
+    int f_addr[2], f_swz[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; k_addr[kb] = r * 128; k_swz[kb] = (r >> 1) & 7; }
-#pragma unroll
-    for (int db = 0; db < 2; ++db) { const int r = db * 32 + l31; v_addr[db] = 8192 + r * 128 + u * 8; v_swz[db] = (r >> 1) & 7; }
+    for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; f_addr[kb] = r * 128; f_swz[kb] = (r >> 1) & 7; }
 
-    const float cs = 0.125f * 1.44269504088896341f;
-    f32x16 oacc[2][2];
-    float m_run[2], l_run[2];
-    int nz = 0;                                           // closed form for absent (all-zero) segments
-    if (p.nseg > 0 && !pres0) nz += p.nk[0];
-    if (p.nseg > 1 && !pres1) nz += p.nk[1];
+    const float cs = 0.125f * 1.44269504088896341f;      // softmax scale (d^-0.5) folded with log2(e)
+    f32x16 oacc[2], sacc[2];
+    v8 pf[4];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int r = 0; r < 16; ++r) { oacc[db][r] = 0.f; sacc[db][r] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[qi][db][r] = 0.f;
-        m_run[qi] = nz > 0 ? 0.f : NEG_BIG;
-        l_run[qi] = (nz > 0 && u == 0) ? (float)nz : 0.f;
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[ks][j] = (T)0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+    {   // closed form for absent (all-zero) segments: nk keys with logit 0, value 0
+        int nz = 0;
+        if (p.nseg > 0 && !pres0) nz += p.nk[0];
+        if (p.nseg > 1 && !pres1) nz += p.nk[1];
+        if (nz > 0) { m_run = 0.f; l_run = u == 0 ? (float)nz : 0.f; }
     }
 
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
-        if (s < nt) issue(s, s);
-    if (nt >= ST - 1) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();      // Q (oldest DMAs, own rows) has landed
-    v8 qf[2][4];
+        if (s <= nt) issue_stage(s, s);
+    if (nt >= ST - 2) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();       // Q (oldest DMAs, own rows) has landed
+    v8 qf[4];
     {
-        const char* dq = smem + ST * 16384 + wave * 8192 + l31 * 128;
+        const char* dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) qf[qi][s] = *(const v8*)(dq + qi * 4096 + (((2 * s + u) ^ ((l31 >> 1) & 7)) << 4));
+        for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(dq + (((2 * s + u) ^ ((l31 >> 1) & 7)) << 4));
     }
 
-    int cbuf = 0, ibuf = ST - 1;
-    for (int t = 0; t < nt; ++t) {
-        if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * IPW>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + ST - 1 < nt) issue(t + ST - 1, ibuf);
-        const char* buf = smem + cbuf * 16384;
-        cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
-        ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
-        const int sg = t < nt0 ? 0 : 1;
-        const int kt = sg ? t - nt0 : t;
-        const int valid = p.nk[sg] - kt * 64;
+    auto k_frag = [&](const char* buf, int kb, int s4) { return *(const v8*)(buf + f_addr[kb] + (((2 * s4 + u) ^ f_swz[kb]) << 4)); };
+    auto v_frag = [&](const char* buf, int db, int ks) { return *(const v8*)(buf + 8192 + f_addr[db] + (((2 * ks + u) ^ f_swz[db]) << 4)); };
 
-        // ---- S^T = K . Q^T for both q-blocks (each K fragment read once) ----
-        f32x16 sacc[2][2];
+    // MFMA block s: PV(s-1) and QK^T(s), interleaved so that consecutive MFMAs never share an accumulator.  The edge blocks
+    // run the same 16 MFMAs on harmless operands (block 0: P = 0 and the zero-filled V^T half; block nt: the zero-filled K
+    // half, result unused) -- two half-blocks per workgroup instead of three code paths in the loop.
+    auto mfma_block = [&](const char* buf) {
+        v8 vf[2][4], kf[2][4];
+        if constexpr (DEEP) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int i = 0; i < 4; ++i) { vf[0][i] = v_frag(buf, 0, i); vf[1][i] = v_frag(buf, 1, i); kf[0][i] = k_frag(buf, 0, i); kf[1][i] = k_frag(buf, 1, i); }
+            __builtin_amdgcn_sched_barrier(0);           // all 16 ds_read_b128 issued before the first MFMA; the waits stay counted
+        }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[qi][kb][r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const v8 kf = *(const v8*)(buf + k_addr[kb] + (((2 * s + u) ^ k_swz[kb]) << 4));
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) sacc[qi][kb] = VT<T>::mfma(kf, qf[qi][s], sacc[qi][kb]);
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (!DEEP) { vf[0][i] = v_frag(buf, 0, i); vf[1][i] = v_frag(buf, 1, i); kf[0][i] = k_frag(buf, 0, i); kf[1][i] = k_frag(buf, 1, i); }
+            oacc[0] = VT<T>::mfma(vf[0][i], pf[i], oacc[0]);
+            oacc[1] = VT<T>::mfma(vf[1][i], pf[i], oacc[1]);
+            if (i == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                sacc[0] = VT<T>::mfma(kf[0][0], qf[0], z);
+                sacc[1] = VT<T>::mfma(kf[1][0], qf[0], z);
+            } else {
+                sacc[0] = VT<T>::mfma(kf[0][i], qf[i], sacc[0]);
+                sacc[1] = VT<T>::mfma(kf[1][i], qf[i], sacc[1]);
             }
         }
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            if (valid < 64) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * u;
-                        if (key >= valid) sacc[qi][kb][r] = NEG_BIG;
-                    }
-            }
-            float mx = NEG_BIG;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qi][kb][r]);
-            mx = xhalf_max(mx);
-            const float m_new = fmaxf(m_run[qi], mx * cs);
-            const bool grew = m_new > m_run[qi];
-            float psum = 0.f;
-            v8 pf[4];
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // VALU block j: online softmax of S^T(j) (this lane: one q row, 32 of the tile's 64 keys) -> P^T(j) as PV B-operand
+    auto valu_block = [&](int j) {
+        const int sg = j < nt0 ? 0 : 1;
+        const int kt = sg ? j - nt0 : j;
+        const int valid = p.nk[sg] - kt * 64;            // keys of this tile that exist (>= 64: all)
+        if (valid < 64) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[qi][kb][r], cs, -m_new));
-                    psum += pv;
-                    pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
-                }
-            if (__any(grew)) {                           // otherwise alpha == 1 exactly for every lane
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
-                l_run[qi] *= alpha;
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
-            }
-            m_run[qi] = m_new;
-            l_run[qi] += psum;
-            // ---- O^T += V^T . P^T ----
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const v4 lo = *(const v4*)(buf + v_addr[db] + (((2 * ks) ^ v_swz[db]) << 4));
-                    const v4 hi = *(const v4*)(buf + v_addr[db] + (((2 * ks + 1) ^ v_swz[db]) << 4));
-                    v8 vf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                    oacc[qi][db] = VT<T>::mfma(vf, pf[ks], oacc[qi][db]);
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * u;
+                    if (key >= valid) sacc[kb][r] = NEG_BIG;
                 }
         }
-    }
-
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const float lt = xhalf_sum(l_run[qi]);
-        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
-        const int q_row = row0 + qi * 32 + l31;
-        if (q_row < p.Nq) {
-            T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 4 * u;
+        float mx = fmaxf(sacc[0][0], sacc[1][0]);       // (built with -fno-honor-nans: fmaxf chains fold to v_max3_f32 without
+#pragma unroll                                           //  a canonicalising v_max per MFMA output)
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+        mx = xhalf_max(mx);
+        const float m_new = fmaxf(m_run, mx * cs);
+        if (__any(m_new > m_run + thr)) {                // some row's max moved by more than thr: move every row's max
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    v4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (T)(oacc[qi][db][4 * g + j] * inv);
-                    *(v4*)(op + db * 32 + 8 * g) = o;
-                }
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            m_run = m_new;
         }
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], cs, -m_run));
+                if (r & 1) ps1 += pv; else ps0 += pv;
+                pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
+            }
+        l_run += ps0 + ps1;
+    };
+
+    // Phase 2s starts with `sync_stage`: wait until this wave's share of stage s has landed (stages s .. s+ST-2 are outstanding,
+    // fewer at the tail), workgroup barrier (=> every share landed, and every wave is done with stage s-1), refill the freed
+    // buffer with stage s+ST-1.  The two groups run separate loops (same barrier count) so that neither carries the other's
+    // register assignment across the blocks.
+    int cbuf = 0, ibuf = ST - 1;
+    auto sync_stage = [&](int s) -> const char* {
+        if (s + ST - 2 <= nt) wait_vmcnt<(ST - 2) * IPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (s + ST - 1 <= nt) issue_stage(s + ST - 1, ibuf);
+        const char* buf = smem + cbuf * 16384;
+        cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
+        ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
+        return buf;
+    };
+    auto mid_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+    if (grp == 0) {
+        for (int s = 0; s <= nt; ++s) {
+            const char* buf = sync_stage(s);             // phase 2s
+            mfma_block(buf);
+            mid_barrier();                               // phase 2s+1
+            if (s < nt) valu_block(s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int s = 0; s <= nt; ++s) {
+            const char* buf = sync_stage(s);             // phase 2s
+            if (s >= 1) valu_block(s - 1);
+            mid_barrier();                               // phase 2s+1
+            mfma_block(buf);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- finalise and store: lane holds O[q][h*64 + db*32 + 8g + 4u + j] ----
+    const float lt = xhalf_sum(l_run);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    if (q_row < p.Nq) {
+        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 4 * u;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (T)(oacc[db][4 * g + j] * inv);
+                *(v4*)(op + db * 32 + 8 * g) = o;
+            }
     }
 }
 
 template <typename T, int MODE>
 static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
-    // tune = (kt << 24) | (rows64 << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
-    // rows64 = 1: 64 query rows per wave (attn64_kernel).
+    // tune = (flags << 24) | (kernel << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
+    // kernel = 2 | 3: attn_pp_kernel (3: one workgroup per CU, deep fragment prefetch); flags: bit0 pair adjacent waves, bit1 no
+    // setprio, bits 2-3 rescale-threshold selector.
     // No tune: 8 waves (256 query rows per workgroup: fewest K/V re-reads) while that still gives most CUs a workgroup,
     // else 4 waves with the 3-stage ring, 2 waves only for tiny problems (measured rule, profiles/r01_tune_report_*.json).
     const long bh = (long)p.B * p.heads;
@@ -477,27 +541,27 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     if (bh * ((p.Nq + 255) / 256) >= 200) { nw = 8; stg = 2; }
     else if (bh * ((p.Nq + 127) / 128) < 64 && p.Nq <= 64) { nw = 2; stg = 2; }
     if (tune) { nw = tune & 0xff; stg = (tune >> 8) & 0xff; }
-    if ((tune >> 16) & 0xff) {                           // 64-row waves (attn64_kernel): SELF mode, 4 waves, ring
-        if (MODE != IDMVTON_ATTN_SELF || nw != 4 || (stg != 3 && stg != 4))
-            return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: 64-row waves need SELF mode, 4 waves, 3 or 4 stages");
+    if (((tune >> 16) & 0xff) == 2 || ((tune >> 16) & 0xff) == 3) {   // ping-pong kernel (3: one workgroup per CU, deep fragment prefetch)
+        const bool deep = ((tune >> 16) & 0xff) == 3;
+        if (MODE != IDMVTON_ATTN_SELF || nw != 8 || (stg != 2 && stg != 3))
+            return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: the ping-pong kernel needs SELF mode, 8 waves, 2 or 3 stages");
+        static const float thr_tab[4] = {4.f, 0.f, 8.f, 2.f};
+        p.pp_flags = (tune >> 24) & 3;
+        p.pp_thr = thr_tab[(tune >> 26) & 3];
         p.nqb = (p.Nq + 255) / 256;
-        const dim3 grid64(p.nqb * p.heads * p.B), block64(256);
-        if (stg == 3) hipLaunchKernelGGL((attn64_kernel<T, 3>), grid64, block64, 0, st, p);
-        else hipLaunchKernelGGL((attn64_kernel<T, 4>), grid64, block64, 0, st, p);
+        const dim3 gridp(p.nqb * p.heads * p.B), blockp(512);
+        const bool prio = !(p.pp_flags & 2);
+#define PP_CASE(ST_, PR_, DP_) if (stg == ST_ && prio == PR_ && deep == DP_) hipLaunchKernelGGL((attn_pp_kernel<T, ST_, PR_, DP_>), gridp, blockp, 0, st, p);
+        PP_CASE(2, true, false) PP_CASE(2, false, false) PP_CASE(3, true, false) PP_CASE(3, false, false)
+        PP_CASE(2, true, true) PP_CASE(2, false, true) PP_CASE(3, true, true) PP_CASE(3, false, true)
+#undef PP_CASE
         CHECK_LAUNCH("attn_fwd");
         return IDMVTON_OK;
     }
+    if ((tune >> 16) & 0xff) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: unknown kernel selector in tune");
     const int qbs = 32 * nw;
     p.nqb = (p.Nq + qbs - 1) / qbs;
     const dim3 grid(p.nqb * p.heads * p.B), block(nw * 64);
-    const int kt2 = (tune >> 24) & 0xf;                  // 2: two 64-key tiles per barrier (two-buffer loop, 4 or 8 waves)
-    if (kt2 == 2) {
-        if (stg != 2 || (nw != 4 && nw != 8)) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: 128-key stages need stages=2, waves 4|8");
-        if (nw == 4) hipLaunchKernelGGL((attn_kernel<T, MODE, 4, 2, 2>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((attn_kernel<T, MODE, 8, 2, 2>), grid, block, 0, st, p);
-        CHECK_LAUNCH("attn_fwd");
-        return IDMVTON_OK;
-    }
 #define ATTN_CASE(NW_, ST_) if (nw == NW_ && stg == ST_) { hipLaunchKernelGGL((attn_kernel<T, MODE, NW_, ST_>), grid, block, 0, st, p); } else
     ATTN_CASE(2, 2) ATTN_CASE(4, 2) ATTN_CASE(8, 2)
     ATTN_CASE(2, 3) ATTN_CASE(4, 3) ATTN_CASE(8, 3)
@@ -521,7 +585,7 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
     CHECK_ARG(a->ldq >= a->heads * 64 && a->ldo >= a->heads * 64, IDMVTON_E_SHAPE, "attn_fwd: ldq/ldo < heads*64");
     AttnParams p;
     p.B = a->B; p.heads = a->heads; p.Nq = a->Nq; p.q = a->q; p.ldq = a->ldq; p.out = a->out; p.ldo = a->ldo;
-    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0;
+    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0; p.pp_flags = 0; p.pp_thr = 4.f;
     const uint64_t qb = ((uint64_t)a->B * a->Nq - 1) * a->ldq * 2 + (uint64_t)a->heads * 128;
     CHECK_ARG(qb < 0x80000000ull, IDMVTON_E_SHAPE, "attn_fwd: Q >= 2 GiB");
     p.qbytes = (uint32_t)qb;

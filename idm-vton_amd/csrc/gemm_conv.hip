@@ -31,7 +31,7 @@ struct GemmParams {
     const void* bias; const void* rowbias; int rowbias_ld; int rows_per_group;
     const void* res; int ldr;
     int mode;
-    void* vt; int vt_n0; int vt_tokens;
+    void* vt; int vt_n0; int vt_tokens; int vt_perm;
     int tiles_m, tiles_n;
 };
 
@@ -265,7 +265,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
                 for (int g = 0; g < 4; ++g) {
                     const int m = m0 + wm * SM + mi * 32 + 8 * g + 4 * u;
                     if (m >= p.M) continue;
-                    const int b = m / p.vt_tokens, tok = m - b * p.vt_tokens;
+                    const int b = m / p.vt_tokens;
+                    int tok = m - b * p.vt_tokens;
+                    // attention key order: bits 2 and 3 of the token index swapped inside every group of 16, so that the 8 keys a
+                    // half-wave contracts in one PV MFMA (QK^T accumulator rows 8g+4u..+3, g = 0,1) are 16 contiguous bytes of V^T
+                    if (p.vt_perm) tok = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
                     v4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
@@ -448,6 +452,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     if (a->bias) CHECK_ARG(((uintptr_t)a->bias & 7) == 0, IDMVTON_E_ALIGN, "gemm_conv: bias alignment");
     if (a->rowbias) CHECK_ARG(a->rowbias_ld % 4 == 0 && a->rows_per_group > 0 && ((uintptr_t)a->rowbias & 7) == 0,
                               IDMVTON_E_ALIGN, "gemm_conv: rowbias");
+    if (a->vt && a->vt_perm) CHECK_ARG(a->vt_tokens % 16 == 0, IDMVTON_E_ARG, "gemm_conv: vt_perm needs vt_tokens %% 16 == 0 (got %d)", a->vt_tokens);
     if (a->vt) CHECK_ARG(a->vt_tokens > 0 && a->vt_tokens % 4 == 0 && a->M % a->vt_tokens == 0 && a->vt_n0 % 64 == 0 &&
                          a->vt_n0 >= 0 && a->vt_n0 < a->N && ((uintptr_t)a->vt & 7) == 0,
                          IDMVTON_E_ARG, "gemm_conv: vt_tokens=%d vt_n0=%d", a->vt_tokens, a->vt_n0);
@@ -459,7 +464,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.M = a->M; p.Ho = a->Ho; p.Wo = a->Wo; p.Hi = a->Hi; p.Wi = a->Wi; p.stride = a->stride; p.ups = a->ups ? 1 : 0;
     p.out = a->out; p.ldo = a->ldo; p.bias = a->bias; p.rowbias = a->rowbias; p.rowbias_ld = a->rowbias_ld;
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1; p.res = a->res; p.ldr = a->ldr; p.mode = a->mode;
-    p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4;
+    p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4; p.vt_perm = a->vt_perm ? 1 : 0;
     p.tiles_m = p.tiles_n = 0;
 
     // Tile choice: tile_hint (variant<<28 | BN<<16 | BM) from the caller's tuning table; GEGLU needs 64-row wave tiles (BN >= 128).

@@ -88,8 +88,10 @@ class SegSpec:
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, vt=None,
-              vt_n0=0, vt_tokens=0, tile_hint=0):
-    """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous."""
+              vt_n0=0, vt_tokens=0, vt_perm=True, tile_hint=0):
+    """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
+    vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
+    kernel's key order (see key_order()), False as a plain transpose."""
     a = ffi.GemmConvArgs()
     a.dtype = _dt(w)
     N, Ktot = w.shape
@@ -116,6 +118,7 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.ldr = (ldr if ldr is not None else (res.stride(-2) if res is not None else 0))
     a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else ffi.EPI_NONE)
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
+    a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))
@@ -128,6 +131,24 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     obytes = (M * (N // 2 if geglu else N)) * esz + (M * N * esz if res is not None else 0)
     _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
+
+
+def key_order_index(n, device=None):
+    """Position -> key index of the attention kernel's V^T key order: inside every group of 16 keys, bits 2 and 3 of the index
+    are swapped (csrc/attention.hip: the 8 keys a half-wave contracts per PV MFMA become one aligned 16-byte read)."""
+    if n % 16:
+        raise ValueError("key order needs a multiple of 16 keys, got %d" % n)
+    i = torch.arange(n, device=device)
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+
+
+def key_order(vt):
+    """[..., keys] plain V^T -> the layout idmvton_attn_fwd consumes (the permutation is an involution)."""
+    return vt.index_select(-1, key_order_index(vt.shape[-1], vt.device)).contiguous()
+
+
+def round16(n):
+    return (n + 15) // 16 * 16
 
 
 def linear(x, w, **kw):

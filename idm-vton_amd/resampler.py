@@ -13,6 +13,7 @@ class HipResampler:
     def __init__(self, state_dict, prefix="", dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, ff_mult=4,
                  dtype=torch.bfloat16, device="cuda"):
         assert dim_head == 64, "HIP attention kernels are specialised for head_dim 64"
+        assert num_queries % 16 == 0, "num_queries must be a multiple of 16 (key-order V^T)"
         self.dtype, self.device = dtype, torch.device(device)
         self.dim, self.depth, self.heads, self.nq = dim, depth, heads, num_queries
         self.inner = dim_head * heads
@@ -23,7 +24,7 @@ class HipResampler:
         """x: [B][n1][embedding_dim] -> [B][num_queries][output_dim]"""
         sd, dt, dev = self.sd, self.dtype, self.device
         B, n1, E = x.shape
-        r1 = (n1 + 7) // 8 * 8                                       # token rows padded: V^T rows 16-byte aligned
+        r1 = ops.round16(n1)                                         # token rows padded: key-order V^T needs multiples of 16
         xp = torch.zeros(B, r1, E, dtype=dt, device=dev)
         xp[:, :n1] = x.to(dev, dt)
         inner, nq, D = self.inner, self.nq, self.dim

@@ -150,16 +150,16 @@ class HipUNet:
 
     def encode_context(self, text, ip=None):
         """Step-invariant cross-attention K / V^T for every attn2 (ip_adapter/attention_processor.py:1957-1958,1978-1979).
-        text: [B][77][xd]; ip: [B][16][xd] image tokens (TryonNet).  Rows are padded to a multiple of 8 with zeros."""
+        text: [B][77][xd]; ip: [B][16][xd] image tokens (TryonNet).  Rows are padded to a multiple of 16 with zeros."""
         dt, dev = self.dtype, self.device
         B, nt, xd = text.shape
-        rt = (nt + 7) // 8 * 8
+        rt = ops.round16(nt)                                 # key-order V^T needs multiples of 16
         tpad = torch.zeros(B, rt, xd, dtype=dt, device=dev)
         tpad[:, :nt] = text.to(dev, dt)
         ctx = dict(B=B, nt=nt, rt=rt, kv={})
         if ip is not None:
             ni = ip.shape[1]
-            ri = (ni + 7) // 8 * 8
+            ri = ops.round16(ni)
             ipad = torch.zeros(B, ri, xd, dtype=dt, device=dev)
             ipad[:, :ni] = ip.to(dev, dt)
             ctx.update(ni=ni, ri=ri)

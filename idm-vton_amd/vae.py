@@ -102,7 +102,7 @@ class HipVAE:
         q = ops.linear(t, sd[p + ".to_q.weight"], bias=sd[p + ".to_q.bias"])
         k = ops.linear(t, sd[p + ".to_k.weight"], bias=sd[p + ".to_k.bias"])
         vt = torch.empty(B, C, N, dtype=dt, device=dev)
-        ops.linear(t, sd[p + ".to_v.weight"], bias=sd[p + ".to_v.bias"], vt=vt, vt_n0=0, vt_tokens=N)
+        ops.linear(t, sd[p + ".to_v.weight"], bias=sd[p + ".to_v.bias"], vt=vt, vt_n0=0, vt_tokens=N, vt_perm=False)
         o = torch.empty(B * N, C, dtype=dt, device=dev)
         for b in range(B):
             s = ops.linear(q[b * N:(b + 1) * N], k[b * N:(b + 1) * N])          # [N][N] scores

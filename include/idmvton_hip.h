@@ -78,6 +78,10 @@ typedef struct {
                                     variant 1 with register-prefetched fragments on every tile; variant 3 (experimental) =
                                     variant 1 with the K walk rotated per tile (plain Linear launches only).
                                     Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */
+    int32_t vt_perm;             /* 1: write vt in the attention kernel's KEY ORDER: inside every group of 16 tokens, bits 2 and 3 of
+                                    the token index are swapped (position p holds token (p&~12)|((p&4)<<1)|((p&8)>>1)), which makes
+                                    the 8 keys one half-wave contracts per PV MFMA one aligned 16-byte read.  Needs vt_tokens % 16 == 0.
+                                    0: plain transpose (the VAE mid block uses V^T as a GEMM weight). */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
 
@@ -92,7 +96,8 @@ int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
  *
  * q   : [B][Nq][ldq]   head h at columns [h*64, h*64+64)
  * k_s : [B_s][k_rows_s][ldk_s] (same head packing; first nk_s rows of each batch are keys)
- * vt_s: V transposed, [B_s][heads*64][ldvt_s] (keys contiguous; ldvt >= roundup8(nk), columns >= nk finite)
+ * vt_s: V transposed, [B_s][heads*64][ldvt_s] in the kernel's KEY ORDER (gemm_conv's vt_perm = 1: bits 2 and 3 of the key
+ *       index swapped inside every group of 16 keys); ldvt >= roundup16(nk), positions of keys >= nk finite
  * Segment s serves batches b >= seg_b0[s], reading its batch (b - seg_b0[s]).  For b < seg_b0[s] the segment's keys
  * are the all-zero garment features of the CFG-unconditional half (src/tryon_pipeline.py:1796): K=V=0 exactly (to_k /
  * to_v have no bias), handled in closed form as `Nk_s` keys with logit 0 and value 0.
@@ -111,8 +116,11 @@ typedef struct {
     int32_t k_rows[2];           /* rows per batch element in k[s] (>= nk; 0 means nk)           */
     int32_t seg_b0[2];
     float ip_scale;
-    int32_t tune;                /* 0 = auto; else (kt<<24)|(rows64<<16)|(stages<<8)|waves (kt=2: two 64-key tiles per barrier, stages=2): stages 2 (two-buffer) | 3 | 4 (LDS ring),
-                                    waves 2|4|8; rows64=1: 64 query rows per wave (SELF mode, 4 waves, ring) */
+    int32_t tune;                /* 0 = auto; else (flags<<24)|(kernel<<16)|(stages<<8)|waves.  kernel 0: attn_kernel, one barrier per 64-key
+                                    tile, stages 2 (two-buffer) | 3 | 4 (LDS ring), waves 2|4|8 (any mode).  kernel 2|3: the ping-pong kernel
+                                    (SELF mode, 8 waves, stages 2|3; 2 = two workgroups per CU, 3 = one per CU with every fragment of a block
+                                    prefetched); flags bit0 = pair waves (w, w^1) instead of (w, w+4), bit1 = no s_setprio, bits 2..3 =
+                                    deferred-rescale threshold selector {0: 4, 1: 0 (exact skip only), 2: 8, 3: 2} in log2 units */
 } idmvton_attn_args;
 int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);
 

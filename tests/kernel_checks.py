@@ -92,10 +92,18 @@ def check_vt(B, Ntok, C, dtype, dev, seed=0, tile_hint=0):
     ref = x.float() @ w.float().t()
     out = torch.zeros(M, 2 * C, dtype=dtype, device=dev)
     vt = torch.zeros(B, C, Ntok, dtype=dtype, device=dev)
-    ops.linear(x, w, out=out, vt=vt, vt_n0=2 * C, vt_tokens=Ntok, tile_hint=tile_hint)
+    vt_ref = ref[:, 2 * C:].reshape(B, Ntok, C).transpose(1, 2)
+    ops.linear(x, w, out=out, vt=vt, vt_n0=2 * C, vt_tokens=Ntok, vt_perm=False, tile_hint=tile_hint)     # plain transpose
     e1 = relerr(out, ref[:, : 2 * C])
-    e2 = relerr(vt, ref[:, 2 * C:].reshape(B, Ntok, C).transpose(1, 2))
-    return max(e1, e2)
+    e2 = relerr(vt, vt_ref)
+    e3 = 0.0
+    if Ntok % 16 == 0:                                   # attention key order (bits 2/3 of the token index swapped per 16)
+        vt2 = torch.zeros(B, C, Ntok, dtype=dtype, device=dev)
+        ops.linear(x, w, out=out, vt=vt2, vt_n0=2 * C, vt_tokens=Ntok, tile_hint=tile_hint)
+        e3 = relerr(vt2, ops.key_order(vt_ref))
+        if not torch.equal(ops.key_order(vt2), vt):      # same values, only the position differs
+            e3 = float("inf")
+    return max(e1, e2, e3)
 
 
 def _nhwc(t):
@@ -153,6 +161,15 @@ def check_conv(B, Cin, Cout, H, W, dtype, dev, k=3, stride=1, ups=False, split=0
 
 
 # ------------------------------------------------------------------------------------------------ attention
+def _key_order_padded(v, nk):
+    """v [B][nk][C] -> (V^T [B][C][round16(nk)] in idmvton_attn_fwd's key order, padded keys zero; row length)."""
+    from idm_vton_amd import ops
+    ld = ops.round16(nk)
+    vt = torch.zeros(v.shape[0], v.shape[2], ld, dtype=v.dtype, device=v.device)
+    vt[:, :, :nk] = v.transpose(1, 2)
+    return ops.key_order(vt), ld
+
+
 def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, tune=0):
     """TryonNet attn1 semantics: keys = [own N tokens ; n_garm garment tokens]; batches < b0 see all-zero garment K/V."""
     from idm_vton_amd import ops
@@ -162,14 +179,14 @@ def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, 
     v1 = _r(B, N, Cc, dtype=dtype, dev=dev, seed=seed + 2)
     sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
     kk, vv = sp(k1), sp(v1)
-    segs = [dict(k=k1, vt=v1.transpose(1, 2).contiguous(), nk=N, ldk=Cc, ldvt=N)]
+    ko = lambda v, nk: _key_order_padded(v, nk)        # [B][nk][C] -> V^T [B][C][round16(nk)] in the kernel's key order
+    vt1, ld1 = ko(v1, N)
+    segs = [dict(k=k1, vt=vt1, nk=N, ldk=Cc, ldvt=ld1)]
     if n_garm:
         Bg = B - b0
         k2 = _r(Bg, n_garm, Cc, dtype=dtype, dev=dev, scale=scale, seed=seed + 3)
         v2 = _r(Bg, n_garm, Cc, dtype=dtype, dev=dev, seed=seed + 4)
-        ld = (n_garm + 7) // 8 * 8
-        vt2 = torch.zeros(Bg, Cc, ld, dtype=dtype, device=dev)
-        vt2[:, :, :n_garm] = v2.transpose(1, 2)
+        vt2, ld = ko(v2, n_garm)
         segs.append(dict(k=k2, vt=vt2, nk=n_garm, ldk=Cc, ldvt=ld, b0=b0))
         z = torch.zeros(b0, heads, n_garm, 64, device=dev)
         kk = torch.cat([kk, torch.cat([z, sp(k2)], dim=0)], dim=2)
@@ -177,6 +194,39 @@ def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, 
     ref = F.scaled_dot_product_attention(sp(q), kk, vv).transpose(1, 2).reshape(B, N, Cc)
     out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
     ops.attention(q, out, segs, heads, tune=tune)
+    return relerr(out, ref)
+
+
+def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
+    """idmvton_attn_args.tune for the ping-pong kernel: 8 waves, `stages` LDS stages, deep=1 -> one workgroup per CU with all
+    fragments prefetched; pair=1 pairs waves (w, w^1); thr selects the deferred-rescale threshold {0: 4, 1: 0, 2: 8, 3: 2}."""
+    return ((thr << 2 | noprio << 1 | pair) << 24) | ((3 if deep else 2) << 16) | (stages << 8) | 8
+
+
+def check_attn_spike(dtype, dev, tune=0, seed=0):
+    """Deferred-rescale branch (the running max is only moved when it grows by more than a threshold): moderate logits for most
+    keys, then a few keys far down the walk (own segment tile 9 and the garment segment) whose logit towers over a subset of
+    rows, so the branch fires late, for some rows only, with O / l already accumulated.  Full-tensor fp32 reference."""
+    from idm_vton_amd import ops
+    B, heads, N = 2, 2, 768
+    Cc = heads * 64
+    g = torch.Generator(device="cpu").manual_seed(1234 + seed)
+    q = torch.randn(B, N, Cc, generator=g)
+    k1 = torch.randn(B, N, Cc, generator=g) * 0.5
+    k2 = torch.randn(B, N, Cc, generator=g) * 0.5
+    v1, v2 = torch.randn(B, N, Cc, generator=g), torch.randn(B, N, Cc, generator=g)
+    for (kk, key, rows, gain) in ((k1, 9 * 64 + 5, slice(0, N, 3), 3.0), (k2, 4 * 64 + 37, slice(1, N, 5), 5.0), (k2, 11 * 64 + 63, slice(2, N, 7), 8.0)):
+        # key `key` points along the mean direction of the chosen query rows: q.k >> every other score for those rows
+        d = q[:, rows].mean(dim=1)
+        kk[:, key] = gain * d / d.norm(dim=-1, keepdim=True).clamp_min(1e-6) * 4.0
+    q, k1, k2, v1, v2 = (t.to(dtype).to(dev) for t in (q, k1, k2, v1, v2))
+    sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), torch.cat([sp(k1), sp(k2)], dim=2), torch.cat([sp(v1), sp(v2)], dim=2))
+    ref = ref.transpose(1, 2).reshape(B, N, Cc)
+    vt1, _ = _key_order_padded(v1, N)
+    vt2, _ = _key_order_padded(v2, N)
+    out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
+    ops.attention(q, out, [dict(k=k1, vt=vt1, nk=N, ldk=Cc, ldvt=N), dict(k=k2, vt=vt2, nk=N, ldk=Cc, ldvt=N)], heads, tune=tune)
     return relerr(out, ref)
 
 
@@ -188,12 +238,11 @@ def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, 
     sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
     segs, ref = [], 0
     for i, (nk, sc) in enumerate(((n_text, 1.0), (n_ip, ip_scale))):
-        rows = (nk + 7) // 8 * 8
+        rows = (nk + 15) // 16 * 16
         k = torch.zeros(B, rows, Cc, dtype=dtype, device=dev)
         k[:, :nk] = _r(B, nk, Cc, dtype=dtype, dev=dev, seed=seed + 10 + i)
         v = _r(B, nk, Cc, dtype=dtype, dev=dev, seed=seed + 20 + i)
-        vt = torch.zeros(B, Cc, rows, dtype=dtype, device=dev)
-        vt[:, :, :nk] = v.transpose(1, 2)
+        vt, _ = _key_order_padded(v, nk)
         segs.append(dict(k=k, vt=vt, nk=nk, ldk=Cc, ldvt=rows, k_rows=rows))
         ref = ref + sc * F.scaled_dot_product_attention(sp(q), sp(k[:, :nk]), sp(v))
     ref = ref.transpose(1, 2).reshape(B, N, Cc)
@@ -351,24 +400,28 @@ def all_checks(dev="cuda"):
                 add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn))
                 add(f"attn_cross_77_16_N768_{tag}", lambda dt=dt, tn=tn: check_attn_cross(4, 4, 768, dt, dev, tune=tn))
                 add(f"attn_cross_scale0.5_N200_{tag}", lambda dt=dt, tn=tn: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5, tune=tn))
-        for nw in (4, 8):                                # two 64-key tiles per LDS stage / barrier
-            tn, tag = (2 << 24) | (2 << 8) | nw, f"k2w{nw}"
-            add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
-            add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn))
-            add(f"attn_self_odd_tiles_N320_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 320, dt, dev, n_garm=192, b0=1, tune=tn))
-            add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
-            add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn))
-            add(f"attn_self_N3072_h10_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=tn))
-            add(f"attn_cross_77_16_N768_{tag}", lambda dt=dt, tn=tn: check_attn_cross(4, 4, 768, dt, dev, tune=tn))
-            add(f"attn_cross_scale0.5_N200_{tag}", lambda dt=dt, tn=tn: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5, tune=tn))
-        for stg in (3, 4):                               # 64 query rows per wave (attn64_kernel)
-            tn, tag = (1 << 16) | (stg << 8) | 4, f"r64s{stg}"
-            add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
-            add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn))
-            add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
-            add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn))
-            add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn))
-            add(f"attn_self_N3072_h10_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=tn))
+        # ping-pong kernel (attn_pp_kernel): every instantiation (stages x priority x prefetch depth), both wave pairings,
+        # every rescale threshold; incl. inputs that FORCE the deferred-rescale branch late in the key walk (spike)
+        for stg in (2, 3):
+            for deep in (0, 1):
+                for noprio in (0, 1):
+                    tn, tag = pp_tune(stg, deep, noprio=noprio), f"pp_s{stg}d{deep}p{1 - noprio}"
+                    add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
+                    add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn))
+                    add(f"attn_self_odd_tiles_N320_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 320, dt, dev, n_garm=192, b0=1, tune=tn))
+                    add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
+                    add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn))
+                    add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn))
+                    add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn))
+            for thr in (1, 2, 3):
+                for pair in (0, 1):
+                    tn, tag = pp_tune(stg, 1, pair=pair, thr=thr), f"pp_s{stg}thr{thr}pair{pair}"
+                    add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
+                    add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
+                    add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn))
+        add("attn_self_N3072_h10_pp_s3d1", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=pp_tune(3, 1)))
+        add("attn_self_N3072_h10_pp_s2d0", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=pp_tune(2, 0)))
+        add("attn_self_spike", lambda dt=dt: check_attn_spike(dt, dev))
         add("attn_self_1seg_N768", lambda dt=dt: check_attn_self(2, 4, 768, dt, dev))
         add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
         add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))

@@ -1,0 +1,165 @@
+"""Round-2 kernel probe (one gpurun call): attention kernel variants and GEMM experiments on the real config-2 / config-4
+shapes, interleaved rounds in one process (median and min per variant), every variant first checked against a torch fp32
+reference of the same op.  Usage: python tools/gpu_r2_probe.py [attn] [gemm]   -> gpurun_out/r2_probe_*.json + stdout table."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from idm_vton_amd import ops  # noqa: E402
+from idm_vton_amd.weights import interleave_geglu  # noqa: E402
+from tests.kernel_checks import pp_tune  # noqa: E402
+
+OUT = os.path.join(ROOT, "gpurun_out")
+DT, DEV = torch.bfloat16, "cuda"
+
+
+def rnd(*s, scale=1.0):
+    return (torch.randn(*s, device=DEV) * scale).to(DT)
+
+
+def time_variants(variants, rounds=7, inner=8, flush=None):
+    """variants: [(tag, thunk)] -> {tag: (median_us, min_us)}; rounds interleaved over the variants."""
+    for _, fn in variants:
+        fn()
+    torch.cuda.synchronize()
+    ts = {tag: [] for tag, _ in variants}
+    for _ in range(rounds):
+        for tag, fn in variants:
+            if flush is not None:
+                flush.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(inner):
+                fn()
+            e1.record()
+            e1.synchronize()
+            ts[tag].append(e0.elapsed_time(e1) * 1e3 / inner)
+    return {tag: (sorted(v)[len(v) // 2], min(v)) for tag, v in ts.items()}
+
+
+def attn_probe():
+    res = {}
+    # (name, B, heads, N, garment keys, b0)
+    shapes = [("tryon_L1 B4 h10 N3072+3072g", 4, 10, 3072, 3072, 2), ("tryon_L2 B4 h20 N768+768g", 4, 20, 768, 768, 2),
+              ("garm_L1 B2 h10 N3072", 2, 10, 3072, 0, 0), ("garm_L2 B2 h20 N768", 2, 20, 768, 0, 0),
+              ("cfg4_L1 B2 h10 N6144+6144g", 2, 10, 6144, 6144, 1), ("cfg4_L2 B2 h20 N1536+1536g", 2, 20, 1536, 1536, 1)]
+    old = [("old_w8s2", (2 << 8) | 8), ("old_w8s3", (3 << 8) | 8), ("old_w4s3", (3 << 8) | 4)]
+    pp = []
+    for stg in (2, 3):
+        for deep in (0, 1):
+            pp.append((f"pp_s{stg}d{deep}", pp_tune(stg, deep)))
+    pp += [("pp_s3d1_noprio", pp_tune(3, 1, noprio=1)), ("pp_s3d1_pair", pp_tune(3, 1, pair=1)), ("pp_s3d1_thr0", pp_tune(3, 1, thr=1)),
+           ("pp_s3d1_thr8", pp_tune(3, 1, thr=2)), ("pp_s3d0_noprio", pp_tune(3, 0, noprio=1)), ("pp_s3d0_pair", pp_tune(3, 0, pair=1)),
+           ("pp_s2d1_noprio", pp_tune(2, 1, noprio=1))]
+    for name, B, heads, N, ng, b0 in shapes:
+        C = heads * 64
+        q, k1, v1 = rnd(B, N, C), rnd(B, N, C), rnd(B, N, C)
+        segs = [dict(k=k1, vt=ops.key_order(v1.transpose(1, 2).contiguous()), nk=N, ldk=C, ldvt=N)]
+        sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+        kk, vv = sp(k1), sp(v1)
+        flops = 4.0 * B * heads * N * N * 64
+        if ng:
+            k2, v2 = rnd(B - b0, ng, C), rnd(B - b0, ng, C)
+            segs.append(dict(k=k2, vt=ops.key_order(v2.transpose(1, 2).contiguous()), nk=ng, ldk=C, ldvt=ng, b0=b0))
+            flops += 4.0 * (B - b0) * heads * N * ng * 64
+            z = torch.zeros(b0, heads, ng, 64, device=DEV)
+            kk = torch.cat([kk, torch.cat([z, sp(k2)], dim=0)], dim=2)
+            vv = torch.cat([vv, torch.cat([z, sp(v2)], dim=0)], dim=2)
+        ref = None
+        if B * heads * N * (N + ng) <= 4 * 20 * 3072 * 6144:
+            ref = F.scaled_dot_product_attention(sp(q), kk, vv).transpose(1, 2).reshape(B, N, C)
+        out = torch.empty(B, N, C, dtype=DT, device=DEV)
+        variants, errs = [], {}
+        for tag, tn in old + pp:
+            out.zero_()
+            try:
+                ops.attention(q, out, segs, heads, tune=tn)
+                torch.cuda.synchronize()
+            except RuntimeError as e:
+                errs[tag] = str(e)[:80]
+                continue
+            if ref is not None:
+                errs[tag] = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+            variants.append((tag, lambda tn=tn: ops.attention(q, out, segs, heads, tune=tn)))
+        t = time_variants(variants, rounds=7, inner=6 if N >= 3072 else 20)
+        res[name] = {tag: dict(us=round(t[tag][0], 1), min_us=round(t[tag][1], 1), tflops=round(flops / t[tag][0] / 1e6, 1),
+                               frac=round(flops / t[tag][0] / 1e6 / 2500, 3), err=errs.get(tag)) for tag in t}
+        res[name]["gflop"] = flops / 1e9
+        print(f"== {name}  ({flops / 1e9:.1f} GFLOP)", flush=True)
+        for tag in t:
+            r = res[name][tag]
+            print(f"   {tag:16s} {r['us']:8.1f} us  (min {r['min_us']:7.1f})  {r['tflops']:7.1f} TF  {100 * r['frac']:5.1f}%  err={r['err']}", flush=True)
+    json.dump(res, open(os.path.join(OUT, "r2_probe_attn.json"), "w"), indent=1)
+
+
+def hint(v, bn, bm):
+    return (v << 28) | (bn << 16) | bm
+
+
+def gemm_probe():
+    """Per shape: tile variants x {cold (L2/MALL flushed: the weights come from HBM as in the real loop), warm (same operands
+    re-used)}, the K-rotated walk (variant 3), and an activation pitch padded by 64 elements (L2 channel spread)."""
+    res = {}
+    flush = torch.empty(640 << 20, dtype=torch.uint8, device=DEV)
+    cases = []
+    x, w, b = rnd(3072, 1280, scale=0.5), rnd(10240, 1280, scale=0.03), rnd(10240, scale=0.1)
+    wi, bi = interleave_geglu(w, b)
+    cases.append(("ff1_geglu 3072x10240x1280", 2.0 * 3072 * 10240 * 1280, lambda h, xx=None: ops.linear(x if xx is None else xx, wi, bias=bi, geglu=True, tile_hint=h), x,
+                  [("r256x256", hint(1, 256, 256)), ("x256x256", hint(3, 256, 256)), ("r128x256", hint(1, 128, 256)), ("x128x256", hint(3, 128, 256))]))
+    for M in (3072, 1536):
+        x2, w2, rs2 = rnd(M, 1280, scale=0.5), rnd(1280, 1280, scale=0.03), rnd(M, 1280)
+        cases.append((f"proj {M}x1280x1280", 2.0 * M * 1280 * 1280, lambda h, xx=None, x2=x2, w2=w2, rs2=rs2: ops.linear(x2 if xx is None else xx, w2, res=rs2, tile_hint=h), x2,
+                      [("r128x128", hint(1, 128, 128)), ("x128x128", hint(3, 128, 128)), ("r128x64", hint(1, 128, 64)), ("x128x64", hint(3, 128, 64)),
+                       ("p64x64", hint(2, 64, 64)), ("v0_128x64", hint(0, 128, 64)), ("v0_64x64", hint(0, 64, 64))]))
+    x4, w4, rs4 = rnd(3072, 5120, scale=0.5), rnd(1280, 5120, scale=0.02), rnd(3072, 1280)
+    cases.append(("ff2 3072x1280x5120", 2.0 * 3072 * 1280 * 5120, lambda h, xx=None: ops.linear(x4 if xx is None else xx, w4, res=rs4, tile_hint=h), x4,
+                  [("r128x128", hint(1, 128, 128)), ("x128x128", hint(3, 128, 128)), ("r128x64", hint(1, 128, 64)), ("x128x64", hint(3, 128, 64))]))
+    x5, w5 = rnd(3072, 1280, scale=0.5), rnd(3840, 1280, scale=0.03)
+    cases.append(("qkv 3072x3840x1280", 2.0 * 3072 * 3840 * 1280, lambda h, xx=None: ops.linear(x5 if xx is None else xx, w5, tile_hint=h), x5,
+                  [("r128x128", hint(1, 128, 128)), ("x128x128", hint(3, 128, 128)), ("r128x256", hint(1, 128, 256)), ("x128x256", hint(3, 128, 256)), ("r256x256", hint(1, 256, 256))]))
+    x6, w6, rs6 = rnd(12288, 640, scale=0.5), rnd(640, 640, scale=0.04), rnd(12288, 640)
+    cases.append(("proj 12288x640x640", 2.0 * 12288 * 640 * 640, lambda h, xx=None: ops.linear(x6 if xx is None else xx, w6, res=rs6, tile_hint=h), x6,
+                  [("r128x128", hint(1, 128, 128)), ("x128x128", hint(3, 128, 128)), ("r128x256", hint(1, 128, 256)), ("r128x64", hint(1, 128, 64))]))
+    for name, fl, fn, xref, vs in cases:
+        ref = fn(vs[0][1]).float()
+        variants_cold, variants_warm, errs = [], [], {}
+        for tag, h in vs:
+            try:
+                o = fn(h).float()
+            except RuntimeError as e:
+                errs[tag] = str(e)[:60]
+                continue
+            errs[tag] = ((o - ref).abs().max() / ref.abs().max()).item()
+            variants_cold.append((tag, lambda h=h: fn(h)))
+            variants_warm.append((tag + "_warm", lambda h=h: fn(h)))
+        # activation with a padded row pitch (K + 64 elements): same values, rows start on different L2 channels
+        M, K = xref.shape
+        big = torch.zeros(M, K + 64, dtype=DT, device=DEV)
+        big[:, :K] = xref
+        xp = big[:, :K]
+        tag0, h0 = vs[0]
+        errs[tag0 + "_xpitch"] = ((fn(h0, xp).float() - ref).abs().max() / ref.abs().max()).item()
+        variants_cold.append((tag0 + "_xpitch", lambda: fn(h0, xp)))
+        tc = time_variants(variants_cold, rounds=7, inner=1, flush=flush)
+        tw = time_variants(variants_warm, rounds=5, inner=10)
+        res[name] = {}
+        print(f"== {name}", flush=True)
+        for tag, (med, mn) in list(tc.items()) + list(tw.items()):
+            res[name][tag] = dict(us=round(med, 1), min_us=round(mn, 1), tflops=round(fl / med / 1e6, 1), err=errs.get(tag.replace("_warm", "")))
+            print(f"   {tag:18s} {med:8.1f} us (min {mn:7.1f})  {fl / med / 1e6:7.1f} TF  err_vs_first={errs.get(tag.replace('_warm', ''))}", flush=True)
+    json.dump(res, open(os.path.join(OUT, "r2_probe_gemm.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    ops.load_tune(None)
+    what = sys.argv[1:] or ["attn", "gemm"]
+    if "attn" in what:
+        attn_probe()
+    if "gemm" in what:
+        gemm_probe()
