@@ -28,11 +28,37 @@ struct AttnParams {
     const void* vt[2]; int ldvt[2]; uint32_t vtbytes[2];
     int nk[2]; int krows[2]; int seg_b0[2];
     float ip_scale;
-    int nqb;
+    int nqb, chunk, parts;
     int pp_flags; float pp_thr;
 };
 
 #define NEG_BIG (-1.0e30f)
+
+
+// Work order.  A (batch, head) group costs in proportion to the key segments present for its batch (the CFG-unconditional
+// batches b < seg_b0 skip the garment segment: half the tiles), and block id i runs on XCD i % 8 in id order.  Groups are
+// therefore ordered longest first (descending b), each group's q-blocks cut into `parts` chunks of `chunk` q-blocks (a unit:
+// its workgroups walk the same K/V, so they share it through one XCD's L2), and the units are dealt round-robin to the XCDs:
+// every XCD -- and, since all of an XCD's workgroups are dispatched in id order, every CU -- gets the same mix of long and
+// short work with the long work first.  (The previous contiguous split gave XCDs 0-3 only unconditional batches: they idled
+// for half of the launch.)  Ids beyond the last unit / q-block are padding and exit.
+__device__ __forceinline__ bool attn_work(const AttnParams& p, int bid, int& b, int& h, int& qb) {
+    const int x = bid & 7, j = bid >> 3;
+    const int u = j / p.chunk, r = j - u * p.chunk;
+    const int U = u * 8 + x;
+    const int g = U / p.parts, part = U - g * p.parts;
+    qb = part * p.chunk + r;
+    b = p.B - 1 - g / p.heads;
+    h = g % p.heads;
+    return g < p.B * p.heads && qb < p.nqb;
+}
+static void attn_grid(AttnParams& p, int qrows, dim3& grid) {
+    p.nqb = (p.Nq + qrows - 1) / qrows;
+    p.chunk = p.nqb >= 8 ? (p.nqb + 1) / 2 : 1;
+    p.parts = (p.nqb + p.chunk - 1) / p.chunk;
+    const int units = p.B * p.heads * p.parts;
+    grid = dim3(8 * ((units + 7) / 8) * p.chunk);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -52,9 +78,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     const int wave = uniform(threadIdx.x >> 6);
     const int u = lane >> 5, l31 = lane & 31;
 
-    const int wg = xcd_remap(blockIdx.x, p.nqb * p.heads * p.B);
-    const int bh = wg / p.nqb, qb = wg - bh * p.nqb;
-    const int b = bh / p.heads, h = bh - b * p.heads;
+    int b, h, qb;
+    if (!attn_work(p, blockIdx.x, b, h, qb)) return;     // block-uniform
 
     // ---- Q fragments (MFMA B operand): column q = l31, k = d in [16s + 8u, +8) ----
     const int q_row = qb * QB + wave * 32 + l31;
@@ -288,7 +313,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 // DEEP = 1: one workgroup per CU (up to 256 VGPRs): every MFMA block reads its 16 fragments from LDS up front (one exposed LDS
 // latency per block); DEEP = 0: 128 VGPRs, two workgroups per CU, fragments read two MFMAs ahead (the other workgroup's waves
 // fill the gaps).
-template <typename T, int ST, bool PRIO, bool DEEP>
+// ABL (measurement only, wrong results): 1 = VALU block reduced to the P conversion (no max / exp / sum), 2 = MFMA block
+// reduced to its LDS reads (no MFMA) -- the template-ablation method of the CDNA guide for finding what bounds a phase.
+template <typename T, int ST, bool PRIO, bool DEEP, int ABL = 0>
 __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnParams p) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
@@ -301,9 +328,8 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
     const int grp = (p.pp_flags & 1) ? (wave & 1) : (wave >> 2);      // wave-uniform
     const float thr = p.pp_thr;
 
-    const int wg = xcd_remap(blockIdx.x, p.nqb * p.heads * p.B);
-    const int bh = wg / p.nqb, qb = wg - bh * p.nqb;
-    const int b = bh / p.heads, h = bh - b * p.heads;
+    int b, h, qb;
+    if (!attn_work(p, blockIdx.x, b, h, qb)) return;     // block-uniform
     const int q_row = qb * QB + wave * 32 + l31;
 
     {   // Q tile of this wave: 32 rows x 128 B -> LDS (4 DMA instructions, K's swizzle)
@@ -417,6 +443,10 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (!DEEP) { vf[0][i] = v_frag(buf, 0, i); vf[1][i] = v_frag(buf, 1, i); kf[0][i] = k_frag(buf, 0, i); kf[1][i] = k_frag(buf, 1, i); }
+            if constexpr (ABL == 2) {                    // keep the reads and the operands alive, issue no MFMA
+                asm volatile("" :: "v"(vf[0][i]), "v"(vf[1][i]), "v"(kf[0][i]), "v"(kf[1][i]), "v"(pf[i]), "v"(qf[i]));
+                continue;
+            }
             oacc[0] = VT<T>::mfma(vf[0][i], pf[i], oacc[0]);
             oacc[1] = VT<T>::mfma(vf[1][i], pf[i], oacc[1]);
             if (i == 0) {
@@ -433,6 +463,14 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
 
     // VALU block j: online softmax of S^T(j) (this lane: one q row, 32 of the tile's 64 keys) -> P^T(j) as PV B-operand
     auto valu_block = [&](int j) {
+        if constexpr (ABL == 1) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pf[kb * 2 + (r >> 3)][r & 7] = (T)sacc[kb][r];
+            l_run += 1.f;
+            return;
+        }
         const int sg = j < nt0 ? 0 : 1;
         const int kt = sg ? j - nt0 : j;
         const int valid = p.nk[sg] - kt * 64;            // keys of this tile that exist (>= 64: all)
@@ -548,8 +586,9 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
         static const float thr_tab[4] = {4.f, 0.f, 8.f, 2.f};
         p.pp_flags = (tune >> 24) & 3;
         p.pp_thr = thr_tab[(tune >> 26) & 3];
-        p.nqb = (p.Nq + 255) / 256;
-        const dim3 gridp(p.nqb * p.heads * p.B), blockp(512);
+        dim3 gridp;
+        attn_grid(p, 256, gridp);
+        const dim3 blockp(512);
         const bool prio = !(p.pp_flags & 2);
 #define PP_CASE(ST_, PR_, DP_) if (stg == ST_ && prio == PR_ && deep == DP_) hipLaunchKernelGGL((attn_pp_kernel<T, ST_, PR_, DP_>), gridp, blockp, 0, st, p);
         PP_CASE(2, true, false) PP_CASE(2, false, false) PP_CASE(3, true, false) PP_CASE(3, false, false)
@@ -558,10 +597,20 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
         CHECK_LAUNCH("attn_fwd");
         return IDMVTON_OK;
     }
+    if (((tune >> 16) & 0xff) == 4 || ((tune >> 16) & 0xff) == 5) {   // ablation builds of the ping-pong kernel (timing only)
+        p.pp_flags = 0; p.pp_thr = 4.f;
+        dim3 gridp;
+        attn_grid(p, 256, gridp);
+        if (MODE != IDMVTON_ATTN_SELF) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: ablation kernels are SELF mode only");
+        if (((tune >> 16) & 0xff) == 4) hipLaunchKernelGGL((attn_pp_kernel<T, 2, true, false, 1>), gridp, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((attn_pp_kernel<T, 2, true, false, 2>), gridp, dim3(512), 0, st, p);
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
     if ((tune >> 16) & 0xff) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: unknown kernel selector in tune");
-    const int qbs = 32 * nw;
-    p.nqb = (p.Nq + qbs - 1) / qbs;
-    const dim3 grid(p.nqb * p.heads * p.B), block(nw * 64);
+    dim3 grid;
+    attn_grid(p, 32 * nw, grid);
+    const dim3 block(nw * 64);
 #define ATTN_CASE(NW_, ST_) if (nw == NW_ && stg == ST_) { hipLaunchKernelGGL((attn_kernel<T, MODE, NW_, ST_>), grid, block, 0, st, p); } else
     ATTN_CASE(2, 2) ATTN_CASE(4, 2) ATTN_CASE(8, 2)
     ATTN_CASE(2, 3) ATTN_CASE(4, 3) ATTN_CASE(8, 3)
@@ -585,7 +634,7 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
     CHECK_ARG(a->ldq >= a->heads * 64 && a->ldo >= a->heads * 64, IDMVTON_E_SHAPE, "attn_fwd: ldq/ldo < heads*64");
     AttnParams p;
     p.B = a->B; p.heads = a->heads; p.Nq = a->Nq; p.q = a->q; p.ldq = a->ldq; p.out = a->out; p.ldo = a->ldo;
-    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0; p.pp_flags = 0; p.pp_thr = 4.f;
+    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0; p.chunk = p.parts = 1; p.pp_flags = 0; p.pp_thr = 4.f;
     const uint64_t qb = ((uint64_t)a->B * a->Nq - 1) * a->ldq * 2 + (uint64_t)a->heads * 128;
     CHECK_ARG(qb < 0x80000000ull, IDMVTON_E_SHAPE, "attn_fwd: Q >= 2 GiB");
     p.qbytes = (uint32_t)qb;

@@ -124,6 +124,39 @@ extern "C" int idmvton_vae_sample(const idmvton_vae_sample_args* a, void* stream
     return IDMVTON_OK;
 }
 
+// ---- weight prefetch: pull a byte range towards the chip (the XCD L2 of the touching block and the Infinity Cache) ----
+// One dword per 128-byte line; nothing is computed.  The loads of a thread are issued back to back and consumed by one empty asm
+// statement at the end, so each wave keeps `PF_UNROLL` lines in flight.  Meant to run on a side stream beside the kernels that
+// precede the consumer of the range (the denoising loop streams ~11 GB of weights per step from HBM, every GEMM's first touch
+// of its weight tile is a cold miss; measured: the same GEMM runs 10-40 % faster when its operands are cache resident).
+#define PF_UNROLL 8
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint32_t* base, uint64_t lines) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    while (i < lines) {
+        uint32_t v[PF_UNROLL];
+#pragma unroll
+        for (int j = 0; j < PF_UNROLL; ++j) {
+            const uint64_t k = i + j * stride;
+            v[j] = k < lines ? base[k * 32] : 0u;    // default cache policy: the line stays in L2 / Infinity Cache
+        }
+#pragma unroll
+        for (int j = 0; j < PF_UNROLL; ++j) asm volatile("" :: "v"(v[j]));
+        i += PF_UNROLL * stride;
+    }
+}
+extern "C" int idmvton_prefetch(const void* ptr, uint64_t bytes, int blocks, void* stream) {
+    CHECK_ARG(ptr != nullptr && ((uintptr_t)ptr & 3) == 0, IDMVTON_E_ARG, "prefetch: pointer");
+    if (bytes < 128) return IDMVTON_OK;
+    const uint64_t lines = bytes / 128;
+    if (blocks <= 0) blocks = 64;
+    const uint64_t need = (lines + 256 * PF_UNROLL - 1) / (256 * PF_UNROLL);
+    if ((uint64_t)blocks > need) blocks = (int)need;
+    hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)ptr, lines);
+    CHECK_LAUNCH("prefetch");
+    return IDMVTON_OK;
+}
+
 // ---- hardware layout probes: one wave, one instruction, raw per-lane operands in, raw per-lane results out ----
 // which = 0: mfma_f32_32x32x16_bf16   a,b: [64 lanes][8] bf16 ; c: [64 lanes][16] f32
 // which = 1: mfma_f32_32x32x16_f16

@@ -39,8 +39,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR, bool KROT = false>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0, const int krot = 0) {
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int NW = WN * WM;
@@ -69,12 +69,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     int x_pix[XI], x_oy[XI], x_ox[XI], x_c8[XI];
     uint32_t x_off[XI];                                  // LIN only
     const int HoWo = p.Ho * p.Wo;
-    // K-tile visited at loop step t: t itself, or (experimental, LIN only) rotated by the tile's position in its XCD patch so
-    // that the tiles sharing operand rows walk K out of phase and only one of them pays each line's first-touch (L2 miss)
-    auto kbyte = [&](int t) -> uint32_t {
-        if constexpr (KROT) { int k = t + krot; const int ntk = p.Ktot >> 6; if (k >= ntk) k -= ntk; return (uint32_t)k * 128u; }
-        else return (uint32_t)t * 128u;
-    };
+    auto kbyte = [&](int t) -> uint32_t { return (uint32_t)t * 128u; };
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int R = (wave * XI + i) * 8 + lrow;
@@ -348,16 +343,19 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 //   v1 (ring)         : 256x256 8 waves ST=2 (128 KiB, 32 B/clk/CU of operand traffic at MFMA peak),
 //                       128x256 8 waves ST=3 (144 KiB, 1 block/CU), 128x128 4 waves ST=3 (96 KiB),
 //                       128x64 4 waves ST=3 (72 KiB, 2 blocks/CU), 64x64 4 waves ST=4 (64 KiB, 2 blocks/CU)
-//   v3 (experimental) : the v1 tiles with each tile's K walk rotated by its position in the XCD patch (plain Linear only;
-//                       changes the fp32 accumulation order per tile; written at the end of round 1, not measured yet)
+//   v4 (deep ring)    : 128x128 ST=5, 128x64 ST=6, 64x128 ST=6, 64x64 ST=8: one block per CU, 112-128 KiB of operand tiles in
+//                       flight.  Measured (profiles/r02_*): a tile's DMA takes ~1.3 us from issue to landed under load, so the
+//                       operand rate a CU sustains is (bytes in flight) / latency -- ring depth, not tile shape, is the lever
+//                       for the launches whose grid (<= 1 tile per CU) cannot use bigger tiles.
+//   (round 1's v3, a per-tile K rotation, was measured in round 2: -0..-35 %, removed.)
 //   v2                : the v1 tiles (except 128x128, which already has it) with the fragments of k-step s+1 read from LDS
 //                       ahead of the MFMAs of step s (PMC: 45 % of wave cycles of the 8-wave tiles sit in s_waitcnt, mostly
 //                       lgkmcnt in front of each k-step; both waves of a SIMD are barrier-aligned so neither covers the other)
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC, bool PFX = false, bool KROT = false>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC, bool PFX = false>
 __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    int tm, tn, krot = 0;
+    int tm, tn;
     if constexpr (!V1) { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
     else {
         // grouped raster: the ~32-64 tiles an XCD runs concurrently form a ~1024 x 1024 output patch (GM m-tiles tall), so
@@ -368,23 +366,19 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
         const int first = grp * GM;
         const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
         tn = rem / gsz; tm = first + (rem - tn * gsz);
-        if constexpr (KROT && LIN) {
-            const int ntk = p.Ktot >> 6;
-            krot = (((tm - first) * ntk) / GM + ((tn & 7) * ntk) / 8) % ntk;
-        }
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true, KROT && LIN>(p, smem, m0, n0, krot);   // block-uniform
-    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false, KROT && LIN>(p, smem, m0, n0, krot);
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true>(p, smem, m0, n0);   // block-uniform
+    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false>(p, smem, m0, n0);
 }
 
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false, bool KROT = false>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
 static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
     if constexpr (V1) {                                  // the v0 kernels keep the one general loader
-        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, true, OCC, PFX, KROT>), grid, block, 0, st, p); return; }
+        if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, true, OCC, PFX>), grid, block, 0, st, p); return; }
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC, PFX>), grid, block, 0, st, p);   // gathers: never rotated
+    hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC, PFX>), grid, block, 0, st, p);
 }
 
 template <typename T>
@@ -410,12 +404,12 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, true, 2, true>(p, lin, st);
         else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, true, 2, true>(p, lin, st);
         else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v2 tile %dx%d", bn, bm);
-    } else if (variant == 3) {                           // EXPERIMENTAL (not yet measured): v1 tiles, K walk rotated per tile (plain Linear only)
-        if (bn == 256 && bm == 256) launch_cfg<T, 256, 256, 2, 4, 2, true, 2, false, true>(p, lin, st);
-        else if (bn == 128 && bm == 256) launch_cfg<T, 128, 256, 2, 4, 3, true, 2, false, true>(p, lin, st);
-        else if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 3, true, 1, false, true>(p, lin, st);
-        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, true, 2, false, true>(p, lin, st);
-        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v3 tile %dx%d", bn, bm);
+    } else if (variant == 4) {                           // deep rings: one block per CU, as many stages as 160 KiB of LDS hold
+        if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 5, true, 1>(p, lin, st);          // 160 KiB, 4 tiles (128 KiB) in flight
+        else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 6, true, 1>(p, lin, st);       // 144 KiB, 5 tiles (120 KiB) in flight
+        else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 8, true, 1>(p, lin, st);         // 128 KiB, 7 tiles (112 KiB) in flight
+        else if (bn == 64 && bm == 128) launch_cfg<T, 64, 128, 2, 2, 6, true, 1>(p, lin, st);       // 144 KiB
+        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v4 tile %dx%d", bn, bm);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;

@@ -76,7 +76,8 @@ STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
-           "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles"]
+           "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles",
+           "idmvton_prefetch"]
 
 _lib = None
 
@@ -110,6 +111,8 @@ def lib():
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]
     L.idmvton_groupnorm_stats_doubles.argtypes = [C.c_int] * 4
     L.idmvton_groupnorm_stats_doubles.restype = C.c_int
+    L.idmvton_prefetch.argtypes = [vp, C.c_uint64, C.c_int, vp]
+    L.idmvton_prefetch.restype = C.c_int
     _lib = L
     return L
 

@@ -202,6 +202,11 @@ typedef struct {
 } idmvton_softmax_args;
 int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream);
 
+/* Weight prefetch: touches one dword per 128-byte line of [ptr, ptr+bytes) from `blocks` workgroups (0 = 64) so the range is
+ * resident in the Infinity Cache / L2 when its consumer starts.  No result; run it on a side stream ahead of the consumer.
+ * (No reference counterpart: the reference streams its weights through cuBLAS/cuDNN kernels with no explicit residency.) */
+int idmvton_prefetch(const void* ptr, uint64_t bytes, int blocks, void* stream);
+
 /* Hardware layout probes (tests/test_probe_gpu.py): run one MFMA / LDS-transpose instruction on caller data. */
 int idmvton_probe_mfma(int which, const void* a, const void* b, float* c, void* stream);
 

@@ -328,13 +328,9 @@ def _hint(variant, bn, bm):
 
 RING_TILES = ((_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
-              (_hint(1, 64, 64), "r64x64"))
-
-
-# Experimental configurations written after the round's GPU budget was spent (compile-verified only): checked only when
-# IDMVTON_EXPERIMENTAL=1, so that the regular `pytest -m gpu` run contains nothing that has never executed on hardware.
-EXPERIMENTAL_TILES = ((_hint(3, 256, 256), "x256x256"), (_hint(3, 128, 256), "x128x256"), (_hint(3, 128, 128), "x128x128"),
-                      (_hint(3, 128, 64), "x128x64"))
+              (_hint(1, 64, 64), "r64x64"),
+              # deep rings (variant 4): one block per CU, 5-8 LDS stages
+              (_hint(4, 128, 128), "d128x128"), (_hint(4, 128, 64), "d128x64"), (_hint(4, 64, 128), "d64x128"), (_hint(4, 64, 64), "d64x64"))
 
 
 def all_checks(dev="cuda"):
@@ -347,16 +343,6 @@ def all_checks(dev="cuda"):
         add("probe_mfma", lambda dt=dt: check_probe_mfma(dt, dev), 1e-6 if dt == torch.float16 else 1e-6)
         for hint, tag in ((0, "auto"), ((128 << 16) | 128, "128x128"), ((128 << 16) | 64, "128x64"), ((64 << 16) | 64, "64x64")):
             add(f"linear_768x640x640_{tag}", lambda dt=dt, hint=hint: check_linear(768, 640, 640, dt, dev, tile_hint=hint))
-        if os.environ.get("IDMVTON_EXPERIMENTAL") == "1":
-            for hint, tag in EXPERIMENTAL_TILES:         # K-rotated walk (plain Linear only; gathers fall back to the unrotated kernel)
-                add(f"exp_linear_768x640x640_{tag}", lambda dt=dt, hint=hint: check_linear(768, 640, 640, dt, dev, tile_hint=hint))
-                add(f"exp_linear_ragged_1000x328x192_{tag}", lambda dt=dt, hint=hint: check_linear(1000, 328, 192, dt, dev, rowbias=True, tile_hint=hint))
-                add(f"exp_linear_K64_{tag}", lambda dt=dt, hint=hint: check_linear(300, 192, 64, dt, dev, tile_hint=hint))
-                add(f"exp_linear_3072x1280x1280_{tag}", lambda dt=dt, hint=hint: check_linear(3072, 1280, 1280, dt, dev, tile_hint=hint))
-                add(f"exp_linear_3072x1280x5120_{tag}", lambda dt=dt, hint=hint: check_linear(3072, 1280, 5120, dt, dev, tile_hint=hint))
-                add(f"exp_vt_B2_N768_C640_{tag}", lambda dt=dt, hint=hint: check_vt(2, 768, 640, dt, dev, tile_hint=hint))
-                add(f"exp_geglu_1536x640_{tag}", lambda dt=dt, hint=hint: check_geglu(1536, 640, dt, dev, tile_hint=hint))
-                add(f"exp_conv3x3_320_32x24_{tag}", lambda dt=dt, hint=hint: check_conv(2, 320, 320, 32, 24, dt, dev, temb=True, tile_hint=hint))
         # LDS-ring variants (tile_hint variant 1): every epilogue / gather mode on every ring tile, incl. M/N tails, K = 1
         # and 2 tiles (shorter than the ring), and tile counts that are not multiples of the raster group
         for hint, tag in RING_TILES:
