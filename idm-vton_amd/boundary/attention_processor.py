@@ -115,9 +115,9 @@ class AttnProcessor2_0(nn.Module):
             if L % 16 == 0:
                 qk = torch.empty(B * L, 2 * inner, dtype=dt, device=dev)
                 vt = torch.empty(B, inner, L, dtype=dt, device=dev)
-                ops.linear(x.reshape(B * L, C), w, bias=b, out=qk, vt=vt, vt_n0=2 * inner, vt_tokens=L)
+                ops.linear(x.reshape(B * L, C), w, bias=b, out=qk, vt=vt, vt_n0=2 * inner, vt_tokens=L, colscale_n=inner, colscale=ops.QSCALE)
                 seg = dict(k=qk[:, inner:], vt=vt, nk=L, ldk=2 * inner, ldvt=L)
-                ops.attention(qk, att, [seg], attn.heads, B=B, Nq=L, ldq=2 * inner, ldo=inner)
+                ops.attention(qk, att, [seg], attn.heads, B=B, Nq=L, ldq=2 * inner, ldo=inner, q_prescaled=True)
                 return _finish(attn, att, residual, shape4, B, L)
             q = ops.linear(x.reshape(B * L, C), w[:inner], bias=None if b is None else b[:inner])
             k, vt, L8 = _project_kv(x, w[inner:], None if b is None else b[inner:], inner)

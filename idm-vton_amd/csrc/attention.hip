@@ -30,6 +30,7 @@ struct AttnParams {
     float ip_scale;
     int nqb, chunk, parts;
     int pp_flags; float pp_thr;
+    int q_prescaled;
 };
 
 #define NEG_BIG (-1.0e30f)
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int db = 0; db < 2; ++db) { const int r = db * 32 + l31; v_addr[db] = 8192 + r * 128; v_swz[db] = (r >> 1) & 7; }
 
-    const float cs = 0.125f * 1.44269504088896341f;      // softmax scale (d^-0.5) folded with log2(e)
+    // softmax scale (d^-0.5) folded with log2(e); 1 when the caller already multiplied Q by it (args flag q_prescaled)
+    const float cs = p.q_prescaled ? 1.0f : 0.125f * 1.44269504088896341f;
     f32x16 oacc[2], ofin[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -307,15 +309,22 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 // same number of barriers (2 per tile + 2).
 // LDS stage s = { K tile s | V^T tile s-1 } (16 KiB): exactly what MFMA block s reads (group 0 in phase 2s, group 1 in phase
 // 2s+1), filled by LDS-DMA ST-1 stages ahead by all 8 waves (2 instructions each), counted vmcnt across the raw barriers.
-// Rescale: the running max is only moved (and O, l rescaled) when some row's max grew by more than `thr` (log2 units); rows
-// keep exponentiating against the older max otherwise (P <= 2^thr, exact in the final normalisation because l carries the same
-// scale).  The decision for tile j is taken in VALU block j, after PV(j-1) has completed and before P(j) is exponentiated.
+// The kernel is VALU-ISSUE bound (PMC, profiles/r02_pmc_attn_v1_sq.txt: 155 VALU instructions per 16 MFMAs, SIMD issue 83 % busy,
+// matrix pipe 41 %), so the softmax is stripped to the instructions that cannot be avoided:
+//   * Q arrives (or is made) pre-multiplied by softmax_scale * log2(e): S is already in log2 units;
+//   * the running max is SUBTRACTED BY THE MFMA: the first QK^T MFMA of a tile takes C = -m (16 registers holding this
+//     lane's -m_run, rewritten only when the max moves), so S' = S - m_run comes out of the matrix pipe and P = exp2(S') is
+//     ONE instruction per element (was v_fma + v_exp);
+//   * the running max is only moved (and O, l rescaled) when some row's S' exceeds `thr` (log2 units); rows keep exponentiating
+//     against the older max otherwise (P <= 2^thr; exact in the final normalisation because l carries the same scale).  The
+//     decision for tile j is taken in VALU block j, after PV(j-1) has completed and before P(j) is exponentiated; on a move
+//     O, l AND the pending S'(j) are brought to the new max (32 extra subtractions, a few tiles per walk).
 // DEEP = 1: one workgroup per CU (up to 256 VGPRs): every MFMA block reads its 16 fragments from LDS up front (one exposed LDS
 // latency per block); DEEP = 0: 128 VGPRs, two workgroups per CU, fragments read two MFMAs ahead (the other workgroup's waves
 // fill the gaps).
 // ABL (measurement only, wrong results): 1 = VALU block reduced to the P conversion (no max / exp / sum), 2 = MFMA block
-// reduced to its LDS reads (no MFMA) -- the template-ablation method of the CDNA guide for finding what bounds a phase.
-template <typename T, int ST, bool PRIO, bool DEEP, int ABL = 0>
+// reduced to its LDS reads (no MFMA), 3 = both (the DMA / barrier / LDS-read skeleton) -- the template-ablation method of the CDNA guide for finding what bounds a phase.
+template <typename T, int ST, bool DEEP, int ABL = 0>
 __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnParams p) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
@@ -355,10 +364,12 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
     // constants here and the in-loop issue is branch-free: offset = rowbase[seg][i] + kt * tstep[seg]; a chunk is fetched iff
     // its smallest key index lim[i] + 64 kt exists (< nk[seg]); everything else (tiles -1 and nt, key tails) reads zeros.
     const int lrow = lane >> 3, lslot = lane & 7;
-    const bool is_k = wave < 4;
+    const int nk0 = p.nk[0], nk1 = p.nk[1];             // in SGPRs: indexing p.nk[] by a loop value makes hipcc re-load it from the
+    const bool is_k = wave < 4;                          // kernarg segment (s_load + lgkmcnt(0)) in every phase
     const int t_shift = is_k ? 0 : 1;                    // this wave's tile of stage s is s - t_shift
     uint32_t rowbase[2][IPW], tstep[2];
-    int lim[IPW];
+    int lim0 = 0;                                        // lim of instruction 0; instruction 1's is lim0 ^ lim_x (one register less)
+    const int lim_x = is_k ? 8 : 32;
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
         const size_t bsg = (size_t)(b - p.seg_b0[sg] > 0 ? b - p.seg_b0[sg] : 0);
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
             rowbase[sg][i] = is_k ? (uint32_t)(((bsg * p.krows[sg] + R) * p.ldk[sg] + h * 64 + c * 8) * 2)
                                   : (uint32_t)(((bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + c * 8) * 2);
             // V^T chunk c holds tile positions [8c, 8c+8) = keys 16(c>>1) + 4(c&1) + {0..3, 8..11} (key order)
-            lim[i] = is_k ? R : 16 * (c >> 1) + 4 * (c & 1);
+            if (i == 0) lim0 = is_k ? R : 16 * (c >> 1) + 4 * (c & 1);     // (R1 = R0 + 8 = R0 ^ 8; c1 = c0 ^ 4 -> +-32)
         }
     }
     const __amdgpu_buffer_rsrc_t rs0 = is_k ? make_rsrc(p.k[0], p.kbytes[0]) : make_rsrc(p.vt[0], p.vtbytes[0]);
@@ -381,13 +392,14 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
         const bool in_range = t >= 0 && t < nt;
         const bool sg1 = t >= nt0;
         const int kt = sg1 ? t - nt0 : t;
-        const int room = in_range ? (sg1 ? p.nk[1] : p.nk[0]) - kt * 64 : 0;       // keys of this tile that exist
+        const int room = in_range ? (sg1 ? nk1 : nk0) - kt * 64 : 0;               // keys of this tile that exist
         const uint32_t toff = (uint32_t)kt * (sg1 ? tstep[1] : tstep[0]);
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
             const uint32_t off = (sg1 ? rowbase[1][i] : rowbase[0][i]) + toff;
-            if (sg1) dma16(rs1, dst + i * 1024, lim[i] < room ? off : OOB_SENTINEL);
-            else dma16(rs0, dst + i * 1024, lim[i] < room ? off : OOB_SENTINEL);
+            const int lim = i == 0 ? lim0 : (lim0 ^ lim_x);
+            if (sg1) dma16(rs1, dst + i * 1024, lim < room ? off : OOB_SENTINEL);
+            else dma16(rs0, dst + i * 1024, lim < room ? off : OOB_SENTINEL);
         }
     };
 
@@ -396,35 +408,43 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; f_addr[kb] = r * 128; f_swz[kb] = (r >> 1) & 7; }
 
-    const float cs = 0.125f * 1.44269504088896341f;      // softmax scale (d^-0.5) folded with log2(e)
-    f32x16 oacc[2], sacc[2];
+    // NEGM: -m_run lives in 16 registers and is subtracted by the MFMA (C operand of the first QK^T MFMA).  Only the 256-register
+    // build has room for it; the 128-register build subtracts in the softmax (v_fma + v_exp per element instead of v_exp).
+    constexpr bool NEGM = DEEP;
+    f32x16 oacc[2], sacc[2], negm;
     v8 pf[4];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[db][r] = 0.f; sacc[db][r] = 0.f; }
 #pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+#pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[ks][j] = (T)0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
-    {   // closed form for absent (all-zero) segments: nk keys with logit 0, value 0
+    // m_run starts at 0 (S' = S).  Without a closed-form segment the first tile FORCES the max to its own row max (whatever its
+    // sign); with one (nk keys of logit 0, value 0: m = 0, l = nk) the ordinary threshold rule applies from the first tile on.
+    float m_run = 0.f, l_run = 0.f;
+    float thr_cur = -3.0e38f, floor_cur = -3.0e38f;      // first tile: the branch below is always taken and delta = the row max
+    {
         int nz = 0;
         if (p.nseg > 0 && !pres0) nz += p.nk[0];
         if (p.nseg > 1 && !pres1) nz += p.nk[1];
-        if (nz > 0) { m_run = 0.f; l_run = u == 0 ? (float)nz : 0.f; }
+        if (nz > 0) { l_run = u == 0 ? (float)nz : 0.f; thr_cur = thr; floor_cur = 0.f; }
     }
 
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (s <= nt) issue_stage(s, s);
     if (nt >= ST - 2) wait_vmcnt<(ST - 1) * IPW>(); else wait_vmcnt<0>();       // Q (oldest DMAs, own rows) has landed
+    // Q fragments (B operand of S^T), kept in registers.  cs: softmax scale folded with log2(e), 1 when q arrives pre-multiplied
+    // (the NEGM build is only launched with a pre-multiplied q: scaling q here would round it a second time).
+    const char* const dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
     v8 qf[4];
-    {
-        const char* dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(dq + (((2 * s + u) ^ ((l31 >> 1) & 7)) << 4));
-    }
+    for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *(const v8*)(dq + (((2 * s4 + u) ^ ((l31 >> 1) & 7)) << 4));
+    const float cs = p.q_prescaled ? 1.0f : 0.125f * 1.44269504088896341f;
 
     auto k_frag = [&](const char* buf, int kb, int s4) { return *(const v8*)(buf + f_addr[kb] + (((2 * s4 + u) ^ f_swz[kb]) << 4)); };
     auto v_frag = [&](const char* buf, int db, int ks) { return *(const v8*)(buf + 8192 + f_addr[db] + (((2 * ks + u) ^ f_swz[db]) << 4)); };
@@ -439,17 +459,19 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
             for (int i = 0; i < 4; ++i) { vf[0][i] = v_frag(buf, 0, i); vf[1][i] = v_frag(buf, 1, i); kf[0][i] = k_frag(buf, 0, i); kf[1][i] = k_frag(buf, 1, i); }
             __builtin_amdgcn_sched_barrier(0);           // all 16 ds_read_b128 issued before the first MFMA; the waits stay counted
         }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (!DEEP) { vf[0][i] = v_frag(buf, 0, i); vf[1][i] = v_frag(buf, 1, i); kf[0][i] = k_frag(buf, 0, i); kf[1][i] = k_frag(buf, 1, i); }
-            if constexpr (ABL == 2) {                    // keep the reads and the operands alive, issue no MFMA
+            if constexpr (ABL == 2 || ABL == 3) {        // keep the reads and the operands alive, issue no MFMA
                 asm volatile("" :: "v"(vf[0][i]), "v"(vf[1][i]), "v"(kf[0][i]), "v"(kf[1][i]), "v"(pf[i]), "v"(qf[i]));
                 continue;
             }
             oacc[0] = VT<T>::mfma(vf[0][i], pf[i], oacc[0]);
             oacc[1] = VT<T>::mfma(vf[1][i], pf[i], oacc[1]);
-            if (i == 0) {
+            if (i == 0 && NEGM) {                        // S' = K.Q^T - m_run: the max subtraction rides on the accumulator input
+                sacc[0] = VT<T>::mfma(kf[0][0], qf[0], negm);
+                sacc[1] = VT<T>::mfma(kf[1][0], qf[0], negm);
+            } else if (i == 0) {
                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 sacc[0] = VT<T>::mfma(kf[0][0], qf[0], z);
                 sacc[1] = VT<T>::mfma(kf[1][0], qf[0], z);
@@ -458,12 +480,11 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
                 sacc[1] = VT<T>::mfma(kf[1][i], qf[i], sacc[1]);
             }
         }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // VALU block j: online softmax of S^T(j) (this lane: one q row, 32 of the tile's 64 keys) -> P^T(j) as PV B-operand
     auto valu_block = [&](int j) {
-        if constexpr (ABL == 1) {
+        if constexpr (ABL == 1 || ABL == 3) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -471,9 +492,8 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
             l_run += 1.f;
             return;
         }
-        const int sg = j < nt0 ? 0 : 1;
-        const int kt = sg ? j - nt0 : j;
-        const int valid = p.nk[sg] - kt * 64;            // keys of this tile that exist (>= 64: all)
+        const bool sg1 = j >= nt0;
+        const int valid = sg1 ? nk1 - (j - nt0) * 64 : nk0 - j * 64;     // keys of this tile that exist (>= 64: all)
         if (valid < 64) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -486,23 +506,29 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
         float mx = fmaxf(sacc[0][0], sacc[1][0]);       // (built with -fno-honor-nans: fmaxf chains fold to v_max3_f32 without
 #pragma unroll                                           //  a canonicalising v_max per MFMA output)
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
-        mx = xhalf_max(mx);
-        const float m_new = fmaxf(m_run, mx * cs);
-        if (__any(m_new > m_run + thr)) {                // some row's max moved by more than thr: move every row's max
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        mx = xhalf_max(mx);                              // this row's max over the tile's 64 keys (NEGM: of S' = S - m_run, else of S)
+        if constexpr (!NEGM) mx = fmaf(mx, cs, -m_run);
+        if (__any(mx > thr_cur)) {                       // wave-uniform; taken on the first tile and when a max moved by > thr
+            const float delta = fmaxf(mx, floor_cur);    // later tiles: the max never moves down
+            const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 0.f));   // (first tile: O = l = 0, keep alpha finite)
             l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-            m_run = m_new;
+            m_run += delta;
+            thr_cur = thr; floor_cur = 0.f;
+            if constexpr (NEGM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sacc[0][r] -= delta; sacc[1][r] -= delta; negm[r] = -m_run; }
+            }
         }
         float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], cs, -m_run));
+                const float pv = __builtin_amdgcn_exp2f(NEGM ? sacc[kb][r] : fmaf(sacc[kb][r], cs, -m_run));
                 if (r & 1) ps1 += pv; else ps0 += pv;
                 pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
             }
@@ -579,8 +605,11 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     if (bh * ((p.Nq + 255) / 256) >= 200) { nw = 8; stg = 2; }
     else if (bh * ((p.Nq + 127) / 128) < 64 && p.Nq <= 64) { nw = 2; stg = 2; }
     if (tune) { nw = tune & 0xff; stg = (tune >> 8) & 0xff; }
+    else if (MODE == IDMVTON_ATTN_SELF && bh * ((p.Nq + 255) / 256) >= 200 && p.Nq >= 1024) {
+        tune = (2 << 16) | (2 << 8) | 8; nw = 8; stg = 2;   // measured (profiles/r02_probe_attn_*): the ping-pong kernel wins on the long walks
+    }
     if (((tune >> 16) & 0xff) == 2 || ((tune >> 16) & 0xff) == 3) {   // ping-pong kernel (3: one workgroup per CU, deep fragment prefetch)
-        const bool deep = ((tune >> 16) & 0xff) == 3;
+        const bool deep = ((tune >> 16) & 0xff) == 3 && p.q_prescaled;   // the deep build needs q pre-multiplied (see NEGM)
         if (MODE != IDMVTON_ATTN_SELF || nw != 8 || (stg != 2 && stg != 3))
             return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: the ping-pong kernel needs SELF mode, 8 waves, 2 or 3 stages");
         static const float thr_tab[4] = {4.f, 0.f, 8.f, 2.f};
@@ -589,21 +618,21 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
         dim3 gridp;
         attn_grid(p, 256, gridp);
         const dim3 blockp(512);
-        const bool prio = !(p.pp_flags & 2);
-#define PP_CASE(ST_, PR_, DP_) if (stg == ST_ && prio == PR_ && deep == DP_) hipLaunchKernelGGL((attn_pp_kernel<T, ST_, PR_, DP_>), gridp, blockp, 0, st, p);
-        PP_CASE(2, true, false) PP_CASE(2, false, false) PP_CASE(3, true, false) PP_CASE(3, false, false)
-        PP_CASE(2, true, true) PP_CASE(2, false, true) PP_CASE(3, true, true) PP_CASE(3, false, true)
-#undef PP_CASE
+        // (s_setprio around the MFMA block was measured: no effect in this structure; the 128-register build exists with 2 stages)
+        if (!deep) hipLaunchKernelGGL((attn_pp_kernel<T, 2, false>), gridp, blockp, 0, st, p);
+        else if (stg == 2) hipLaunchKernelGGL((attn_pp_kernel<T, 2, true>), gridp, blockp, 0, st, p);
+        else hipLaunchKernelGGL((attn_pp_kernel<T, 3, true>), gridp, blockp, 0, st, p);
         CHECK_LAUNCH("attn_fwd");
         return IDMVTON_OK;
     }
-    if (((tune >> 16) & 0xff) == 4 || ((tune >> 16) & 0xff) == 5) {   // ablation builds of the ping-pong kernel (timing only)
+    if (((tune >> 16) & 0xff) >= 4 && ((tune >> 16) & 0xff) <= 6) {   // ablation builds of the ping-pong kernel (timing only)
         p.pp_flags = 0; p.pp_thr = 4.f;
         dim3 gridp;
         attn_grid(p, 256, gridp);
         if (MODE != IDMVTON_ATTN_SELF) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: ablation kernels are SELF mode only");
-        if (((tune >> 16) & 0xff) == 4) hipLaunchKernelGGL((attn_pp_kernel<T, 2, true, false, 1>), gridp, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((attn_pp_kernel<T, 2, true, false, 2>), gridp, dim3(512), 0, st, p);
+        if (((tune >> 16) & 0xff) == 4) hipLaunchKernelGGL((attn_pp_kernel<T, 2, false, 1>), gridp, dim3(512), 0, st, p);
+        else if (((tune >> 16) & 0xff) == 5) hipLaunchKernelGGL((attn_pp_kernel<T, 2, false, 2>), gridp, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((attn_pp_kernel<T, 2, false, 3>), gridp, dim3(512), 0, st, p);
         CHECK_LAUNCH("attn_fwd");
         return IDMVTON_OK;
     }
@@ -634,7 +663,7 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
     CHECK_ARG(a->ldq >= a->heads * 64 && a->ldo >= a->heads * 64, IDMVTON_E_SHAPE, "attn_fwd: ldq/ldo < heads*64");
     AttnParams p;
     p.B = a->B; p.heads = a->heads; p.Nq = a->Nq; p.q = a->q; p.ldq = a->ldq; p.out = a->out; p.ldo = a->ldo;
-    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0; p.chunk = p.parts = 1; p.pp_flags = 0; p.pp_thr = 4.f;
+    p.nseg = a->nseg; p.ip_scale = a->ip_scale; p.nqb = 0; p.chunk = p.parts = 1; p.pp_flags = 0; p.pp_thr = 4.f; p.q_prescaled = a->q_prescaled ? 1 : 0;
     const uint64_t qb = ((uint64_t)a->B * a->Nq - 1) * a->ldq * 2 + (uint64_t)a->heads * 128;
     CHECK_ARG(qb < 0x80000000ull, IDMVTON_E_SHAPE, "attn_fwd: Q >= 2 GiB");
     p.qbytes = (uint32_t)qb;

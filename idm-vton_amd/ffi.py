@@ -26,13 +26,13 @@ class GemmConvArgs(C.Structure):
                 ("M", i32), ("Ho", i32), ("Wo", i32), ("Hi", i32), ("Wi", i32), ("stride", i32), ("ups", i32),
                 ("out", vp), ("ldo", i32), ("bias", vp), ("rowbias", vp), ("rowbias_ld", i32),
                 ("rows_per_group", i32), ("res", vp), ("ldr", i32), ("mode", i32), ("vt", vp), ("vt_n0", i32),
-                ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32)]
+                ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("colscale_n", i32), ("colscale", f32), ("prefetch", vp), ("prefetch_bytes", u32)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("mode", i32), ("B", i32), ("heads", i32), ("Nq", i32), ("q", vp), ("ldq", i32),
                 ("out", vp), ("ldo", i32), ("nseg", i32), ("k", vp * 2), ("ldk", i32 * 2), ("vt", vp * 2),
-                ("ldvt", i32 * 2), ("nk", i32 * 2), ("k_rows", i32 * 2), ("seg_b0", i32 * 2), ("ip_scale", f32), ("tune", i32)]
+                ("ldvt", i32 * 2), ("nk", i32 * 2), ("k_rows", i32 * 2), ("seg_b0", i32 * 2), ("ip_scale", f32), ("tune", i32), ("q_prescaled", i32)]
 
 
 class LayerNormArgs(C.Structure):

@@ -78,6 +78,56 @@ def _ptr(t):
     return None if t is None else _dev(t).data_ptr()
 
 
+class PrefetchPlan:
+    """Order of the weight matrices one forward pass launches, so that every GEMM launch can touch the NEXT launch's weights
+    (idmvton_gemm_conv_args.prefetch).  The first pass under the plan records the sequence; later passes replay it and check
+    every launch against the record (a divergent control flow switches the plan off instead of prefetching the wrong range)."""
+
+    def __init__(self):
+        self.seq, self.pos, self.recording, self.ok = [], 0, True, True
+
+    def begin(self):
+        if self.recording and self.seq:
+            self.recording = False                        # second pass: replay
+        self.pos = 0
+
+    def step(self, w):
+        if not self.ok:
+            return None
+        if self.recording:
+            self.seq.append(w)
+            return None
+        i = self.pos
+        self.pos += 1
+        if i >= len(self.seq) or self.seq[i].data_ptr() != w.data_ptr():
+            self.ok = False
+            return None
+        return self.seq[(i + 1) % len(self.seq)]
+
+
+_PLAN = None                                             # the active PrefetchPlan (set by prefetch_plan())
+PREFETCH_ENABLED = os.environ.get("IDMVTON_NO_PREFETCH", "") != "1"
+
+
+class prefetch_plan:
+    """Context manager: GEMM launches inside it follow (and on the first pass record) `plan`."""
+
+    def __init__(self, plan):
+        self.plan = plan if PREFETCH_ENABLED else None
+
+    def __enter__(self):
+        global _PLAN
+        self.prev, _PLAN = _PLAN, self.plan
+        if self.plan is not None:
+            self.plan.begin()
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _PLAN
+        _PLAN = self.prev
+        return False
+
+
 class SegSpec:
     """One K-segment of the virtual activation matrix (see include/idmvton_hip.h, idmvton_seg)."""
     __slots__ = ("t", "coff", "len", "dy", "dx")
@@ -88,7 +138,7 @@ class SegSpec:
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, vt=None,
-              vt_n0=0, vt_tokens=0, vt_perm=True, tile_hint=0):
+              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
     kernel's key order (see key_order()), False as a plain transpose."""
@@ -119,6 +169,11 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else ffi.EPI_NONE)
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
+    a.colscale_n, a.colscale = colscale_n, colscale
+    if _PLAN is not None:
+        nxt = _PLAN.step(w)
+        if nxt is not None:
+            a.prefetch, a.prefetch_bytes = nxt.data_ptr(), nxt.numel() * nxt.element_size()
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))
@@ -163,7 +218,10 @@ def conv_segs(x, k, pad, coff=0, length=None):
     return [SegSpec(x, coff, length, ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
 
 
-def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, Nq=None, ldq=None, ldo=None, tune=0):
+QSCALE = 0.125 * 1.4426950408889634          # softmax_scale(d=64) * log2(e): what `q_prescaled` means
+
+
+def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, Nq=None, ldq=None, ldo=None, tune=0, q_prescaled=False):
     """q/out: [B][Nq][>=heads*64] views; segs: list of dict(k=, vt=, nk=, ldk=, ldvt=, k_rows=, b0=)."""
     a = ffi.AttnArgs()
     a.dtype, a.mode = _dt(q), mode
@@ -178,6 +236,7 @@ def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, 
         a.ldk[i], a.ldvt[i] = s["ldk"], s["ldvt"]
         a.nk[i], a.k_rows[i], a.seg_b0[i] = s["nk"], s.get("k_rows", 0), s.get("b0", 0)
     a.ip_scale = ip_scale
+    a.q_prescaled = int(bool(q_prescaled))
     a.tune = tune if tune else _TUNE["attn"].get(attn_key(a), 0)
     if RECORD is not None:
         RECORD.append(("attn", attn_key(a), type(a).from_buffer_copy(a), (q, out, segs)))

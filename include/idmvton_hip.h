@@ -46,7 +46,7 @@ int idmvton_sizeof(const char* struct_name); /* sizeof() of an args struct by na
  * (torch.cat at unet_block_hacked_tryon.py:2346,2482) are extra segments on a second pointer; the 1x1 conv_shortcut
  * is fused as extra centre-tap segments with its weights appended along K.
  * W is [N][Ktot] (K contiguous: nn.Linear layout; conv weights pre-permuted to [Cout][ky][kx][Cin]).
- * Epilogue: + bias[n] + rowbias[(m / rows_per_group)*rowbias_ld + n] + res[m*ldr + n]; mode GEGLU multiplies the two
+ * Epilogue: (+ bias[n] + rowbias[(m / rows_per_group)*rowbias_ld + n]) [* colscale for n < colscale_n] + res[m*ldr + n]; mode GEGLU multiplies the two
  * 32-row halves of each 64-row weight block (weights pre-interleaved [32 h | 32 gate]) -> out has N/2 columns.
  * Columns n >= vt_n0 (when vt != NULL) are written TRANSPOSED to vt[(b*(N-vt_n0) + n-vt_n0)*vt_tokens + tok] with
  * (b, tok) = divmod(m, vt_tokens): the V^T layout the attention kernel consumes.
@@ -75,13 +75,17 @@ typedef struct {
     void* vt; int32_t vt_n0; int32_t vt_tokens;
     int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
-                                    variant 1 with register-prefetched fragments on every tile; variant 3 (experimental) =
-                                    variant 1 with the K walk rotated per tile (plain Linear launches only).
+                                    variant 1 with register-prefetched fragments on every tile.
                                     Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */
     int32_t vt_perm;             /* 1: write vt in the attention kernel's KEY ORDER: inside every group of 16 tokens, bits 2 and 3 of
                                     the token index are swapped (position p holds token (p&~12)|((p&4)<<1)|((p&8)>>1)), which makes
                                     the 8 keys one half-wave contracts per PV MFMA one aligned 16-byte read.  Needs vt_tokens % 16 == 0.
                                     0: plain transpose (the VAE mid block uses V^T as a GEMM weight). */
+    int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
+                                    before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
+                                    already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */
+    const void* prefetch; uint32_t prefetch_bytes; /* optional: a byte range (the NEXT launch's weight matrix) this launch touches once per
+                                    128-byte line so that it is cache resident when its consumer starts; NULL / 0 = off */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
 
@@ -121,6 +125,8 @@ typedef struct {
                                     (SELF mode, 8 waves, stages 2|3; 2 = two workgroups per CU, 3 = one per CU with every fragment of a block
                                     prefetched); flags bit0 = pair waves (w, w^1) instead of (w, w+4), bit1 = no s_setprio, bits 2..3 =
                                     deferred-rescale threshold selector {0: 4, 1: 0 (exact skip only), 2: 8, 3: 2} in log2 units */
+    int32_t q_prescaled;         /* 1: q is already multiplied by softmax_scale * log2(e) = 0.125 * 1.4426950408889634 (gemm_conv's colscale
+                                    applies it in fp32 in the projection epilogue, same single rounding as an unscaled q) */
 } idmvton_attn_args;
 int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);
 

@@ -170,7 +170,21 @@ def _key_order_padded(v, nk):
     return ops.key_order(vt), ld
 
 
-def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, tune=0):
+def _run_attn(q, out, segs, heads, tune, prescaled, sp, kk, vv, ref):
+    """Launch SELF attention on q (or, prescaled: on q * softmax_scale * log2e rounded to the storage dtype, against the reference
+    of that rounded q) and return the max-rel error."""
+    from idm_vton_amd import ops
+    if prescaled:
+        qs = (q.float() * ops.QSCALE).to(q.dtype)
+        B, N, Cc = q.shape
+        ref = F.scaled_dot_product_attention(sp(qs) / ops.QSCALE, kk, vv).transpose(1, 2).reshape(B, N, Cc)
+        ops.attention(qs, out, segs, heads, tune=tune, q_prescaled=True)
+    else:
+        ops.attention(q, out, segs, heads, tune=tune)
+    return relerr(out, ref)
+
+
+def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, tune=0, prescaled=False):
     """TryonNet attn1 semantics: keys = [own N tokens ; n_garm garment tokens]; batches < b0 see all-zero garment K/V."""
     from idm_vton_amd import ops
     Cc = heads * 64
@@ -193,17 +207,18 @@ def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, 
         vv = torch.cat([vv, torch.cat([z, sp(v2)], dim=0)], dim=2)
     ref = F.scaled_dot_product_attention(sp(q), kk, vv).transpose(1, 2).reshape(B, N, Cc)
     out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
-    ops.attention(q, out, segs, heads, tune=tune)
-    return relerr(out, ref)
+    return _run_attn(q, out, segs, heads, tune, prescaled, sp, kk, vv, ref)
 
 
 def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
-    """idmvton_attn_args.tune for the ping-pong kernel: 8 waves, `stages` LDS stages, deep=1 -> one workgroup per CU with all
-    fragments prefetched; pair=1 pairs waves (w, w^1); thr selects the deferred-rescale threshold {0: 4, 1: 0, 2: 8, 3: 2}."""
+    """idmvton_attn_args.tune for the ping-pong kernel: 8 waves; deep=0 -> 128 registers, two workgroups per CU (2 LDS stages);
+    deep=1 -> one workgroup per CU, `stages` LDS stages, all fragments prefetched, max subtraction on the matrix pipe (needs a
+    pre-multiplied q, else the deep=0 build runs); pair=1 pairs waves (w, w^1); thr selects the deferred-rescale threshold
+    {0: 4, 1: 0, 2: 8, 3: 2}."""
     return ((thr << 2 | noprio << 1 | pair) << 24) | ((3 if deep else 2) << 16) | (stages << 8) | 8
 
 
-def check_attn_spike(dtype, dev, tune=0, seed=0):
+def check_attn_spike(dtype, dev, tune=0, seed=0, prescaled=False):
     """Deferred-rescale branch (the running max is only moved when it grows by more than a threshold): moderate logits for most
     keys, then a few keys far down the walk (own segment tile 9 and the garment segment) whose logit towers over a subset of
     rows, so the branch fires late, for some rows only, with O / l already accumulated.  Full-tensor fp32 reference."""
@@ -226,8 +241,65 @@ def check_attn_spike(dtype, dev, tune=0, seed=0):
     vt1, _ = _key_order_padded(v1, N)
     vt2, _ = _key_order_padded(v2, N)
     out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
-    ops.attention(q, out, [dict(k=k1, vt=vt1, nk=N, ldk=Cc, ldvt=N), dict(k=k2, vt=vt2, nk=N, ldk=Cc, ldvt=N)], heads, tune=tune)
+    segs = [dict(k=k1, vt=vt1, nk=N, ldk=Cc, ldvt=N), dict(k=k2, vt=vt2, nk=N, ldk=Cc, ldvt=N)]
+    return _run_attn(q, out, segs, heads, tune, prescaled, sp, torch.cat([sp(k1), sp(k2)], dim=2), torch.cat([sp(v1), sp(v2)], dim=2), ref)
+
+
+def check_attn_neg(dtype, dev, tune=0, prescaled=False):
+    """Every logit strongly negative (q = -k direction): the running max must follow the data down, not stay at its start value."""
+    from idm_vton_amd import ops
+    B, heads, N = 1, 2, 192
+    Cc = heads * 64
+    g = torch.Generator(device="cpu").manual_seed(77)
+    base = torch.randn(B, 1, Cc, generator=g)
+    q = (base * 6 + 0.3 * torch.randn(B, N, Cc, generator=g)).to(dtype).to(dev)
+    k = (-base * 6 + 0.3 * torch.randn(B, N, Cc, generator=g)).to(dtype).to(dev)       # q.k ~ -36 * 64 / 8 = -290 after scaling
+    v = torch.randn(B, N, Cc, generator=g).to(dtype).to(dev)
+    sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, N, Cc)
+    vt, ld = _key_order_padded(v, N)
+    out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
+    return _run_attn(q, out, [dict(k=k, vt=vt, nk=N, ldk=Cc, ldvt=ld)], heads, tune, prescaled, sp, sp(k), sp(v), ref)
+
+
+def check_colscale(dtype, dev):
+    """Column scaling in the GEMM epilogue: (x W^T + b) * s for the first n columns, before the residual."""
+    from idm_vton_amd import ops
+    M, N, K = 300, 192, 128
+    x, w, b, rs = _r(M, K, dtype=dtype, dev=dev), _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=1), _r(N, dtype=dtype, dev=dev, seed=2), _r(M, N, dtype=dtype, dev=dev, seed=3)
+    ref = x.float() @ w.float().t() + b.float()
+    ref[:, :64] *= ops.QSCALE
+    ref = ref + rs.float()
+    out = ops.linear(x, w, bias=b, res=rs, colscale_n=64, colscale=ops.QSCALE)
     return relerr(out, ref)
+
+
+def check_prefetch(dtype, dev, tile_hint):
+    """A launch that also touches another buffer (the next launch's weights): same result bit for bit, the touched buffer intact;
+    ranges that are not a multiple of the per-block slice / smaller than one line / large (26 MB) all go through."""
+    from idm_vton_amd import ffi, ops
+    M, N, K = 1000, 328, 192
+    x, w, b = _r(M, K, dtype=dtype, dev=dev), _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=1), _r(N, dtype=dtype, dev=dev, seed=2)
+    ref = ops.linear(x, w, bias=b, tile_hint=tile_hint)
+    worst = 0.0
+    for nbytes in (64, 128 * 1000 + 4, 26 << 20):
+        nxt = torch.arange(nbytes // 4, dtype=torch.int32, device=dev)
+        keep = nxt.clone()
+        a = None
+
+        class _P:                                        # a one-step plan: the next "weight" is nxt
+            ok, recording = True, False
+
+            def begin(self): pass
+
+            def step(self, w_): return nxt
+        with ops.prefetch_plan(_P()):
+            out = ops.linear(x, w, bias=b, tile_hint=tile_hint)
+        torch.cuda.synchronize()
+        if not torch.equal(out, ref) or not torch.equal(nxt, keep):
+            return float("inf")
+        worst = max(worst, relerr(out, ref))
+    return worst
 
 
 def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, seed=0, tune=0):
@@ -328,9 +400,7 @@ def _hint(variant, bn, bm):
 
 RING_TILES = ((_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
-              (_hint(1, 64, 64), "r64x64"),
-              # deep rings (variant 4): one block per CU, 5-8 LDS stages
-              (_hint(4, 128, 128), "d128x128"), (_hint(4, 128, 64), "d128x64"), (_hint(4, 64, 128), "d64x128"), (_hint(4, 64, 64), "d64x64"))
+              (_hint(1, 64, 64), "r64x64"))
 
 
 def all_checks(dev="cuda"):
@@ -389,25 +459,34 @@ def all_checks(dev="cuda"):
         # ping-pong kernel (attn_pp_kernel): every instantiation (stages x priority x prefetch depth), both wave pairings,
         # every rescale threshold; incl. inputs that FORCE the deferred-rescale branch late in the key walk (spike)
         for stg in (2, 3):
-            for deep in (0, 1):
-                for noprio in (0, 1):
-                    tn, tag = pp_tune(stg, deep, noprio=noprio), f"pp_s{stg}d{deep}p{1 - noprio}"
-                    add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
-                    add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn))
-                    add(f"attn_self_odd_tiles_N320_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 320, dt, dev, n_garm=192, b0=1, tune=tn))
-                    add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
-                    add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn))
-                    add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn))
-                    add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn))
+            for deep in (0, 1):                          # deep builds are only launched with a pre-multiplied q (else: the 128-register build)
+                for pre in (False, True):
+                    tn, tag = pp_tune(stg, deep), f"pp_s{stg}d{deep}{'q' if pre else ''}"
+                    add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn, prescaled=pre))
+                    add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn, prescaled=pre))
+                    add(f"attn_self_odd_tiles_N320_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_self(2, 2, 320, dt, dev, n_garm=192, b0=1, tune=tn, prescaled=pre))
+                    add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn, prescaled=pre))
+                    add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn, prescaled=pre))
+                    add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_self(1, 3, 1000, dt, dev, tune=tn, prescaled=pre))
+                    add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_spike(dt, dev, tune=tn, prescaled=pre))
+                    add(f"attn_self_neg_logits_{tag}", lambda dt=dt, tn=tn, pre=pre: check_attn_neg(dt, dev, tune=tn, prescaled=pre))
             for thr in (1, 2, 3):
                 for pair in (0, 1):
-                    tn, tag = pp_tune(stg, 1, pair=pair, thr=thr), f"pp_s{stg}thr{thr}pair{pair}"
-                    add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn))
-                    add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn))
-                    add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn))
+                    for deep in (0, 1):
+                        tn, tag = pp_tune(stg, deep, pair=pair, thr=thr), f"pp_s{stg}d{deep}thr{thr}pair{pair}"
+                        add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn, prescaled=True))
+                        add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn, prescaled=True))
+                        add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn, prescaled=True))
         add("attn_self_N3072_h10_pp_s3d1", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=pp_tune(3, 1)))
         add("attn_self_N3072_h10_pp_s2d0", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=pp_tune(2, 0)))
         add("attn_self_spike", lambda dt=dt: check_attn_spike(dt, dev))
+        for tn, tag in ((0, "auto"), ((2 << 8) | 8, "w8s2"), ((3 << 8) | 4, "w4s3"), (pp_tune(2, 0), "pp_s2d0"), (pp_tune(3, 1), "pp_s3d1")):
+            add(f"attn_self_prescaled_2seg_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn, prescaled=True))
+            add(f"attn_self_prescaled_ragged_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn, prescaled=True))
+            add(f"attn_self_neg_logits_{tag}", lambda dt=dt, tn=tn: check_attn_neg(dt, dev, tune=tn))
+        add("linear_colscale", lambda dt=dt: check_colscale(dt, dev))
+        for hint, tag in RING_TILES + ((_hint(0, 128, 128), "v0_128x128"), (_hint(0, 64, 64), "v0_64x64")):
+            add(f"linear_prefetch_{tag}", lambda dt=dt, hint=hint: check_prefetch(dt, dev, hint))
         add("attn_self_1seg_N768", lambda dt=dt: check_attn_self(2, 4, 768, dt, dev))
         add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
         add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))

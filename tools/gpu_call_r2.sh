@@ -1,21 +1,12 @@
 #!/bin/bash
-# round 2, GPU call B: new attention kernels -- sanity (short timeout), kernel parity checks, variant timing; GEMM experiments
+# round 2, GPU call E: kernel checks (attention final variants, prefetch, colscale), bench with / without prefetch, re-tune, bench
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-timeout 120 python - > $O/r2b_sanity.log 2>&1 <<'PY'
-import torch
-from tests import kernel_checks as kc
-for dt in (torch.bfloat16, torch.float16):
-    for tn, tag in ((kc.pp_tune(2, 0), "s2d0"), (kc.pp_tune(3, 1), "s3d1"), (0, "auto")):
-        e = kc.check_attn_self(4, 4, 768, dt, "cuda", n_garm=768, b0=2, tune=tn); torch.cuda.synchronize()
-        print(dt, tag, "2seg", e, flush=True)
-        e = kc.check_attn_self(2, 2, 200, dt, "cuda", n_garm=200, b0=1, tune=tn); torch.cuda.synchronize()
-        print(dt, tag, "ragged", e, flush=True)
-    print(dt, "cross", kc.check_attn_cross(4, 4, 768, dt, "cuda"), flush=True)
-    print(dt, "vt", kc.check_vt(2, 768, 640, dt, "cuda"), flush=True)
-PY
-echo "sanity rc=$?"; cat $O/r2b_sanity.log | tail -20
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=line -p no:cacheprovider -k "attn or vt or probe or ring or gpu_available" > $O/r2b_pytest_attn.log 2>&1; echo "pytest rc=$?"; tail -15 $O/r2b_pytest_attn.log
-timeout 600 python tools/gpu_r2_probe.py attn > $O/r2b_probe_attn.log 2>&1; echo "attn probe rc=$?"; tail -100 $O/r2b_probe_attn.log
-timeout 600 python tools/gpu_r2_probe.py gemm > $O/r2b_probe_gemm.log 2>&1; echo "gemm probe rc=$?"; tail -80 $O/r2b_probe_gemm.log
+timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=line -p no:cacheprovider -k "attn or vt or probe or colscale or prefetch or gpu_available" > $O/r2e_pytest_attn.log 2>&1; echo "pytest rc=$?"; tail -8 $O/r2e_pytest_attn.log
+timeout 600 python tools/gpu_r2_probe.py attn > $O/r2e_probe_attn.log 2>&1; echo "attn probe rc=$?"; grep -A7 "tryon_L1\|tryon_L2" $O/r2e_probe_attn.log
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2e_bench_pf.json 2> $O/r2e_bench_pf.err; echo "bench(prefetch) rc=$?"; cut -c1-1500 $O/r2e_bench_pf.json
+IDMVTON_NO_PREFETCH=1 timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2e_bench_nopf.json 2> $O/r2e_bench_nopf.err; echo "bench(no prefetch) rc=$?"; cut -c1-1500 $O/r2e_bench_nopf.json
+timeout 1500 python tools/gpu_tune.py > $O/r2e_tune.log 2>&1; echo "tune rc=$?"; tail -4 $O/r2e_tune.log
+cp $O/tune_gfx950.json $R/idm-vton_amd/tune_gfx950.json
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2e_bench_tuned.json 2> $O/r2e_bench_tuned.err; echo "bench(tuned) rc=$?"; cut -c1-1500 $O/r2e_bench_tuned.json

@@ -29,7 +29,6 @@ def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
     return ((thr << 2 | noprio << 1 | pair) << 24) | ((3 if deep else 2) << 16) | (stages << 8) | 8
 
 
-GEMM_CANDS += [("d_128x128", hint(4, 128, 128)), ("d_128x64", hint(4, 128, 64)), ("d_64x128", hint(4, 64, 128)), ("d_64x64", hint(4, 64, 64))]
 ATTN_CANDS = [(f"w{nw}s{st}", (st << 8) | nw) for nw in (2, 4, 8) for st in (2, 3, 4)] + \
              [(f"pp_s{st}d{dp}", pp_tune(st, dp)) for st in (2, 3) for dp in (0, 1)]
 
@@ -46,7 +45,7 @@ def main():
     args = ap.parse_args()
     import bench
     from idm_vton_amd import ffi, ops
-    gemm_cands = [c for c in GEMM_CANDS if not (args.skip_ring and c[0][:2] in ("r_", "p_", "d_"))]
+    gemm_cands = [c for c in GEMM_CANDS if not (args.skip_ring and c[0][:2] in ("r_", "p_"))]
     attn_cands = [] if args.skip_attn_variants else ATTN_CANDS
     ops.load_tune(None)                                  # tune from the built-in heuristics, not from a previous table
     dev, dt = torch.device("cuda", 0), torch.bfloat16
@@ -77,12 +76,25 @@ def main():
     def run(fn, a):
         ffi.call(fn, a, stream)
 
+    import ctypes as C
+    L = ffi.lib()
+
+    def touch(ptr, nbytes):
+        if ptr and nbytes >= 128:
+            L.idmvton_prefetch(C.c_void_p(ptr), C.c_uint64(nbytes), 0, C.c_void_p(stream))
+
     def timed(fn, a):
         for _ in range(2):
             run(fn, a)
         ts = []
         for _ in range(args.iters):
             flush.zero_()
+            if fn == "idmvton_gemm_conv":
+                # the state the real loop launches in: weights prefetched by the previous GEMM, activations just written by the
+                # previous kernel -- both cache resident (Infinity Cache), nothing L2-hot from an earlier repetition
+                touch(a.w, a.N * a.Ktot * 2)
+                for i in range(a.nseg):
+                    touch(a.seg[i].ptr, a.seg[i].bytes)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run(fn, a)
