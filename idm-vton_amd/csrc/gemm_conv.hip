@@ -33,7 +33,6 @@ struct GemmParams {
     int mode;
     void* vt; int vt_n0; int vt_tokens; int vt_perm;
     int colscale_n; float colscale;
-    const void* pf; uint32_t pf_bytes;                   // next launch's weights: touched once per 128-byte line by this launch
     int tiles_m, tiles_n;
 };
 
@@ -42,7 +41,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0, const int wg) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int NW = WN * WM;
@@ -58,23 +57,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     const int wave = uniform(threadIdx.x >> 6);
     const int wn = wave / WM, wm = wave % WM;
     const int u = lane >> 5, l31 = lane & 31;
-
-    // ---- prefetch of the NEXT launch's weights (idmvton_gemm_conv_args.prefetch): every workgroup touches its slice, one dword
-    // per 128-byte line, by LDS-DMA into a scratch area nobody reads -- no register destination, nothing to wait for.  The
-    // lines travel HBM -> Infinity Cache / L2 while this launch computes; the next launch's first touch of its weight tiles is
-    // then a cache hit instead of a ~2 us HBM miss on the critical path of every K step (measured on MI355X, activations warm:
-    // 3072x1280x1280 26.7 -> 23.8 us, 1536x1280x5120 51.2 -> 34.8 us, 3072x1280x5120 66.2 -> 53.5 us; profiles/r02_probe_gemm_v3.log).
-    // Issued before the first tile's DMA: vmcnt retires in order, so they sit in front of a first tile that misses HBM anyway.
-    if (p.pf_bytes) {                                    // block-uniform
-        const __amdgpu_buffer_rsrc_t rs_pf = make_rsrc(p.pf, p.pf_bytes);
-        const uint32_t lines = p.pf_bytes >> 7, nblk = (uint32_t)(p.tiles_m * p.tiles_n);
-        const uint32_t per = (lines + nblk - 1) / nblk, l0 = (uint32_t)wg * per;
-        char* scratch = smem + ST * (WBYTES + XBYTES) + wave * 256;
-        for (uint32_t i = wave * 64; i < per; i += NW * 64) {     // wave-uniform trip count
-            const uint32_t li = i + lane, line = l0 + li;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pf, LDS_PTR(scratch), 4, (li < per && line < lines) ? line * 128u : OOB_SENTINEL, 0, 0, 0);
-        }
-    }
 
     // ---- loader state: this lane's rows / swizzled chunk for each DMA instruction it issues ----
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -368,13 +350,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 //                       128x64 4 waves ST=3 (72 KiB, 2 blocks/CU), 64x64 4 waves ST=4 (64 KiB, 2 blocks/CU)
 //   (round 2 measured and removed two ideas: v3 = a per-tile K rotation, -0..-35 %; v4 = deep rings of 5-8 stages with one
 //    block per CU, +-0 % on every shape: the operand stream is not bound by bytes in flight per CU but by the chip-wide L2 ->
-//    LDS rate, ~10-12 TB/s with all 256 CUs streaming, so a launch's ceiling is its tile's arithmetic intensity times that.)
+//    LDS rate, ~10-12 TB/s with all 256 CUs streaming, so a launch's ceiling is its tile's arithmetic intensity times that.
+//    A third: every launch touching the NEXT launch's weights (one dword per line, LDS-DMA into scratch) so they are cache
+//    resident at its start -- -10..-32 % per launch in isolation behind a cache flush, +-0 in the pipeline (GEMM time per
+//    denoising step 46.6 vs 46.3 ms, profiles/r02_bench_prefetch_ab.txt): removed.)
 //   v2                : the v1 tiles (except 128x128, which already has it) with the fragments of k-step s+1 read from LDS
 //                       ahead of the MFMAs of step s (PMC: 45 % of wave cycles of the 8-wave tiles sit in s_waitcnt, mostly
 //                       lgkmcnt in front of each k-step; both waves of a SIMD are barrier-aligned so neither covers the other)
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, int OCC, bool PFX = false>
 __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128 + 2048];   // + 256 B per wave of prefetch scratch
+    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tm, tn;
     if constexpr (!V1) { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
@@ -389,8 +374,8 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
         tn = rem / gsz; tm = first + (rem - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true>(p, smem, m0, n0, wg);   // block-uniform
-    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false>(p, smem, m0, n0, wg);
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true>(p, smem, m0, n0);   // block-uniform
+    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false>(p, smem, m0, n0);
 }
 
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
@@ -454,7 +439,6 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     CHECK_ARG(wbytes + (uint64_t)128 * a->Ktot * 2 < 0xFFFFFFFFull, IDMVTON_E_SHAPE, "gemm_conv: weight too large");
     const bool geglu = a->mode == IDMVTON_EPI_GEGLU;
     CHECK_ARG(a->mode == IDMVTON_EPI_NONE || a->mode == IDMVTON_EPI_GELU || geglu, IDMVTON_E_ARG, "gemm_conv: mode %d", a->mode);
-    if (a->prefetch) CHECK_ARG(((uintptr_t)a->prefetch & 3) == 0 && a->prefetch_bytes < 0x80000000u, IDMVTON_E_ARG, "gemm_conv: prefetch range");
     CHECK_ARG(a->colscale_n >= 0 && a->colscale_n % 4 == 0 && !(geglu && a->colscale_n), IDMVTON_E_ARG, "gemm_conv: colscale_n=%d", a->colscale_n);
     if (geglu) CHECK_ARG(a->N % 64 == 0 && !a->res && !a->rowbias && !a->vt, IDMVTON_E_ARG, "gemm_conv: GEGLU needs N%%64==0, no res/rowbias/vt");
     CHECK_ARG(a->out || (a->vt && a->vt_n0 == 0), IDMVTON_E_ARG, "gemm_conv: null out");
@@ -477,7 +461,6 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1; p.res = a->res; p.ldr = a->ldr; p.mode = a->mode;
     p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4; p.vt_perm = a->vt_perm ? 1 : 0;
     p.colscale_n = a->colscale_n; p.colscale = a->colscale;
-    p.pf = a->prefetch; p.pf_bytes = a->prefetch ? a->prefetch_bytes : 0;
     p.tiles_m = p.tiles_n = 0;
 
     // Tile choice: tile_hint (variant<<28 | BN<<16 | BM) from the caller's tuning table; GEGLU needs 64-row wave tiles (BN >= 128).

@@ -78,56 +78,6 @@ def _ptr(t):
     return None if t is None else _dev(t).data_ptr()
 
 
-class PrefetchPlan:
-    """Order of the weight matrices one forward pass launches, so that every GEMM launch can touch the NEXT launch's weights
-    (idmvton_gemm_conv_args.prefetch).  The first pass under the plan records the sequence; later passes replay it and check
-    every launch against the record (a divergent control flow switches the plan off instead of prefetching the wrong range)."""
-
-    def __init__(self):
-        self.seq, self.pos, self.recording, self.ok = [], 0, True, True
-
-    def begin(self):
-        if self.recording and self.seq:
-            self.recording = False                        # second pass: replay
-        self.pos = 0
-
-    def step(self, w):
-        if not self.ok:
-            return None
-        if self.recording:
-            self.seq.append(w)
-            return None
-        i = self.pos
-        self.pos += 1
-        if i >= len(self.seq) or self.seq[i].data_ptr() != w.data_ptr():
-            self.ok = False
-            return None
-        return self.seq[(i + 1) % len(self.seq)]
-
-
-_PLAN = None                                             # the active PrefetchPlan (set by prefetch_plan())
-PREFETCH_ENABLED = os.environ.get("IDMVTON_NO_PREFETCH", "") != "1"
-
-
-class prefetch_plan:
-    """Context manager: GEMM launches inside it follow (and on the first pass record) `plan`."""
-
-    def __init__(self, plan):
-        self.plan = plan if PREFETCH_ENABLED else None
-
-    def __enter__(self):
-        global _PLAN
-        self.prev, _PLAN = _PLAN, self.plan
-        if self.plan is not None:
-            self.plan.begin()
-        return self.plan
-
-    def __exit__(self, *exc):
-        global _PLAN
-        _PLAN = self.prev
-        return False
-
-
 class SegSpec:
     """One K-segment of the virtual activation matrix (see include/idmvton_hip.h, idmvton_seg)."""
     __slots__ = ("t", "coff", "len", "dy", "dx")
@@ -170,10 +120,6 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.colscale_n, a.colscale = colscale_n, colscale
-    if _PLAN is not None:
-        nxt = _PLAN.step(w)
-        if nxt is not None:
-            a.prefetch, a.prefetch_bytes = nxt.data_ptr(), nxt.numel() * nxt.element_size()
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))

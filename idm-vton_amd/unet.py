@@ -59,7 +59,6 @@ class HipUNet:
         self._prep()
         self._gn_stats = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=self.device)
         self._ctx = None
-        self._plans = {}                                  # PrefetchPlan per forward signature (launch order of the weights)
 
     # ------------------------------------------------------------------------------------------------ weight prep
     def _prep(self):
@@ -297,12 +296,6 @@ class HipUNet:
         """x: NHWC [B][H*W][cin_pad] (channels >= in_channels zero); temb: [B][sum Cout] (time_embeddings()[step]);
         ctx: encode_context(); garment_feats: list of [Bg][N][C] (Bg <= B; batches < B-Bg see all-zero features).
         Returns (noise NHWC [B][H*W][n_out] for TryonNet | None, exported features for GarmentNet)."""
-        key = (B, H, W, garment_feats is not None, garment_kv is not None)
-        plan = self._plans.setdefault(key, ops.PrefetchPlan())
-        with ops.prefetch_plan(plan):                    # every GEMM touches the next GEMM's weights (csrc/gemm_conv.hip)
-            return self._forward(x, temb, ctx, B, H, W, garment_feats, garment_kv, feats_buf)
-
-    def _forward(self, x, temb, ctx, B, H, W, garment_feats=None, garment_kv=None, feats_buf=None):
         topo = self.topo
         garment = dict(feats=garment_feats, kv=garment_kv, feats_buf=feats_buf, idx=0)
         feats = []

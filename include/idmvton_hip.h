@@ -84,8 +84,6 @@ typedef struct {
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */
-    const void* prefetch; uint32_t prefetch_bytes; /* optional: a byte range (the NEXT launch's weight matrix) this launch touches once per
-                                    128-byte line so that it is cache resident when its consumer starts; NULL / 0 = off */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
 

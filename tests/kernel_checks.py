@@ -274,34 +274,6 @@ def check_colscale(dtype, dev):
     return relerr(out, ref)
 
 
-def check_prefetch(dtype, dev, tile_hint):
-    """A launch that also touches another buffer (the next launch's weights): same result bit for bit, the touched buffer intact;
-    ranges that are not a multiple of the per-block slice / smaller than one line / large (26 MB) all go through."""
-    from idm_vton_amd import ffi, ops
-    M, N, K = 1000, 328, 192
-    x, w, b = _r(M, K, dtype=dtype, dev=dev), _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=1), _r(N, dtype=dtype, dev=dev, seed=2)
-    ref = ops.linear(x, w, bias=b, tile_hint=tile_hint)
-    worst = 0.0
-    for nbytes in (64, 128 * 1000 + 4, 26 << 20):
-        nxt = torch.arange(nbytes // 4, dtype=torch.int32, device=dev)
-        keep = nxt.clone()
-        a = None
-
-        class _P:                                        # a one-step plan: the next "weight" is nxt
-            ok, recording = True, False
-
-            def begin(self): pass
-
-            def step(self, w_): return nxt
-        with ops.prefetch_plan(_P()):
-            out = ops.linear(x, w, bias=b, tile_hint=tile_hint)
-        torch.cuda.synchronize()
-        if not torch.equal(out, ref) or not torch.equal(nxt, keep):
-            return float("inf")
-        worst = max(worst, relerr(out, ref))
-    return worst
-
-
 def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, seed=0, tune=0):
     """IPAttnProcessor2_0 semantics: SDPA over text keys + ip_scale * SDPA over image keys."""
     from idm_vton_amd import ops
@@ -485,8 +457,6 @@ def all_checks(dev="cuda"):
             add(f"attn_self_prescaled_ragged_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn, prescaled=True))
             add(f"attn_self_neg_logits_{tag}", lambda dt=dt, tn=tn: check_attn_neg(dt, dev, tune=tn))
         add("linear_colscale", lambda dt=dt: check_colscale(dt, dev))
-        for hint, tag in RING_TILES + ((_hint(0, 128, 128), "v0_128x128"), (_hint(0, 64, 64), "v0_64x64")):
-            add(f"linear_prefetch_{tag}", lambda dt=dt, hint=hint: check_prefetch(dt, dev, hint))
         add("attn_self_1seg_N768", lambda dt=dt: check_attn_self(2, 4, 768, dt, dev))
         add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
         add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))

