@@ -2,6 +2,9 @@
 
   resampler_ref.safetensors  -- weights, input and output of the REFERENCE's own ip_adapter/resampler.py imported verbatim
                                 (the one hot-path file that imports without diffusers): pins oracle/resampler.py.
+  reference_unet_tiny.safetensors -- outputs of the REFERENCE's own TryonNet / GarmentNet forwards, hacked transformer blocks
+                                and attention processors on seeded tiny inputs (oracle/make_golden_ref.py; diffusers supplied by
+                                the test-only stand-in tests/compat/refstub): pins oracle/unet.py and oracle/layers.py.
   reference_signatures.json  -- argument lists of the reference's call surface for this path (ast-parsed): pins the
                                 drop-in boundary (tests/test_boundary_cpu.py).
   tiny_pipeline.safetensors  -- oracle outputs (garment features, TryonNet eps, per-step latents, image) of the tiny
@@ -93,11 +96,25 @@ def signatures_fixture():
         json.dump(reference_signatures(), f, indent=1, sort_keys=True)
 
 
+def reference_unet_fixture(out=None):
+    """tests/golden/reference_unet_tiny.safetensors: outputs of the REFERENCE's own UNet / transformer-block / attention-processor
+    code (oracle/make_golden_ref.py, run in a subprocess that cannot see this repository's src/ and ip_adapter/ packages)."""
+    import subprocess
+    out = out or os.path.join(OUT, "reference_unet_tiny.safetensors")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden_ref.py"), out], cwd="/tmp", env=env,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("make_golden_ref.py failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+    return out
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     signatures_fixture()
     if "--signatures-only" in sys.argv:
         sys.exit(0)
     resampler_fixture()
+    reference_unet_fixture()
     tiny_pipeline_fixture()
     print("wrote", os.listdir(OUT))

@@ -1,0 +1,132 @@
+"""Runs the REFERENCE'S OWN first-party hot-path code on seeded tiny inputs and writes golden vectors that pin `oracle/`.
+TEST INFRASTRUCTURE (see oracle/__init__.py); runs only where /root/reference exists (the build container).
+
+What is executed from /root/reference, unmodified, imported by path with `tests/compat/refstub` standing in for the absent
+`diffusers==0.25.0` (third-party layers written from that release's published semantics; first-party code is the reference's):
+
+  ip_adapter/attention_processor.py   AttnProcessor2_0.__call__ (:203-278), IPAttnProcessor2_0.__call__ (:1907-2010)
+  src/attentionhacked_tryon.py        BasicTransformerBlock.forward (:284-415) incl. the garment concat / truncation
+  src/attentionhacked_garmnet.py      BasicTransformerBlock.forward (:284-406) incl. the norm1 export
+  src/transformerhacked_*.py          Transformer2DModel.forward (:246-467 / :246-460)
+  src/unet_block_hacked_*.py          CrossAttnDown/Up, Down/Up, Mid block forwards and skip handling
+  src/unet_hacked_tryon.py            UNet2DConditionModel.__init__ + forward (:1006-1395), IP processors installed at :773-791
+  src/unet_hacked_garmnet.py          UNet2DConditionModel.forward (:917-1284) -> ((sample,), garment_features)
+
+This script must NOT see the repository root on sys.path: the repo's own `src/` and `ip_adapter/` packages (the product's
+import-path mirrors) would shadow the reference's.  oracle/make_golden.py launches it as a subprocess with cwd=/tmp.
+
+  python oracle/make_golden_ref.py <out.safetensors>
+"""
+import importlib.util
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("IDMVTON_REFERENCE", "/root/reference")
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != ROOT]
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, "tests", "compat", "refstub"))
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+pc = _load("idmvton_config_for_golden", os.path.join(ROOT, "idm-vton_amd", "config.py"))
+
+# The tiny configuration of tests/parity_utils.py, with the Resampler the reference hard-codes (unet_hacked_tryon.py:474-485).
+TINY = dict(block_out_channels=(64, 128, 256), transformer_layers_per_block=(1, 1, 2), num_attention_heads=(1, 2, 4),
+            cross_attention_dim=128, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32,
+            encoder_hid_dim=128, resampler=dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, ff_mult=4))
+
+
+def ref_unet_kwargs(cfg):
+    kw = dict(sample_size=16, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+              down_block_types=cfg.down_block_types, up_block_types=cfg.up_block_types,
+              block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              cross_attention_dim=cfg.cross_attention_dim, transformer_layers_per_block=cfg.transformer_layers_per_block,
+              attention_head_dim=cfg.num_attention_heads, use_linear_projection=True, norm_num_groups=cfg.norm_num_groups,
+              norm_eps=cfg.norm_eps)
+    if cfg.mode == "tryon":
+        kw.update(addition_embed_type=cfg.addition_embed_type, addition_time_embed_dim=cfg.addition_time_embed_dim,
+                  projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim,
+                  encoder_hid_dim=cfg.encoder_hid_dim, encoder_hid_dim_type=cfg.encoder_hid_dim_type)
+    return kw
+
+
+@torch.no_grad()
+def main(out_path):
+    from src.unet_hacked_tryon import UNet2DConditionModel as RefTryon
+    from src.unet_hacked_garmnet import UNet2DConditionModel as RefGarm
+    from src.attentionhacked_tryon import BasicTransformerBlock as RefBlockT
+    from src.attentionhacked_garmnet import BasicTransformerBlock as RefBlockG
+    from ip_adapter.attention_processor import AttnProcessor2_0 as RefAttnProc, IPAttnProcessor2_0 as RefIPProc
+    import src.unet_hacked_tryon as m_t
+    assert m_t.__file__.startswith(REF), m_t.__file__
+
+    t = {}
+    tcfg = pc.UNetConfig(mode="tryon", in_channels=13, **TINY)
+    gcfg = pc.UNetConfig(mode="garmnet", in_channels=4, addition_embed_type=None, encoder_hid_dim_type=None, **TINY)
+    sd_t = pc.random_state_dict(pc.unet_param_shapes(tcfg), 101, torch.float32, "cpu")
+    sd_g = pc.random_state_dict(pc.unet_param_shapes(gcfg), 102, torch.float32, "cpu")
+
+    # ---- whole UNets: state-dict keys/shapes must match the reference classes STRICTLY (pins SURVEY.md Appendix C) ----
+    ref_t = RefTryon(**ref_unet_kwargs(tcfg)).eval()
+    ref_g = RefGarm(**ref_unet_kwargs(gcfg)).eval()
+    ref_t.load_state_dict(sd_t, strict=True)
+    ref_g.load_state_dict(sd_g, strict=True)
+    g = torch.Generator().manual_seed(2024)
+    r = lambda *s: torch.randn(*s, generator=g)
+    B, h, w = 1, 16, 16
+    cloth_lat, cloth_text = r(B, 4, h, w), r(B, 77, 128)
+    (g_sample,), feats = ref_g(cloth_lat, 481, cloth_text, return_dict=False)
+    t["garm.cloth_lat"], t["garm.cloth_text"] = cloth_lat, cloth_text
+    for i, f in enumerate(feats):
+        t[f"garm.feat{i:02d}"] = f
+    t["garm.sample"] = g_sample                         # the (discarded) output of the last executed up block
+
+    lmi, pe = r(2 * B, 13, h, w), r(2 * B, 77, 128)
+    add_text, ip_states = r(2 * B, 64), r(2 * B, 257, 128)
+    time_ids = torch.tensor([[128, 128, 0, 0, 128, 128]], dtype=torch.float32).repeat(2 * B, 1)
+    image_embeds = ref_t.encoder_hid_proj(ip_states)                                  # tryon_pipeline.py:1726
+    feats_cfg = [torch.cat([torch.zeros_like(f), f]) for f in feats]                  # tryon_pipeline.py:1796
+    eps = ref_t(lmi, 481, pe, added_cond_kwargs=dict(text_embeds=add_text, time_ids=time_ids, image_embeds=image_embeds),
+                garment_features=feats_cfg, return_dict=False)[0]
+    t.update({"tryon.lmi": lmi, "tryon.pe": pe, "tryon.add_text": add_text, "tryon.ip_states": ip_states,
+              "tryon.image_embeds": image_embeds, "tryon.eps": eps})
+
+    # ---- single hacked transformer blocks ----
+    dim, heads, hd, xd = 64, 1, 64, 64
+    bt = RefBlockT(dim, heads, hd, cross_attention_dim=xd).eval()
+    bt.attn1.set_processor(RefAttnProc())
+    bt.attn2.set_processor(RefIPProc(hidden_size=dim, cross_attention_dim=xd, num_tokens=16))
+    bg = RefBlockG(dim, heads, hd, cross_attention_dim=xd).eval()
+    gen = torch.Generator().manual_seed(7)
+    for name, blk in (("blk_t", bt), ("blk_g", bg)):
+        for k, v in blk.state_dict().items():
+            v.copy_(torch.randn(v.shape, generator=gen) * (0.05 if v.dim() > 1 else 0.3) + (1.0 if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k.endswith("norm3.weight") else 0.0))
+            t[f"{name}.sd.{k}"] = v.clone()
+    x, garm, enc_t, enc_g = r(2, 40, dim), r(2, 40, dim), r(2, 77 + 16, xd), r(2, 77, xd)
+    y_t, _ = bt(x, encoder_hidden_states=enc_t, garment_features=[garm], curr_garment_feat_idx=0)
+    y_g, exported = bg(x, encoder_hidden_states=enc_g)
+    t.update({"blk.x": x, "blk.garm": garm, "blk.enc_t": enc_t, "blk.enc_g": enc_g, "blk_t.y": y_t, "blk_g.y": y_g,
+              "blk_g.feat": exported[0]})
+
+    save_file({k: v.contiguous() for k, v in t.items()}, out_path,
+              metadata={"generator": "oracle/make_golden_ref.py", "reference": REF, "n_garm_feats": str(len(feats)),
+                        "weights": "config.random_state_dict seeds 101 (tryon) / 102 (garmnet), fp32, std 0.02",
+                        "wsum_t": repr(float(sum(v.double().abs().sum() for v in sd_t.values()))),
+                        "wsum_g": repr(float(sum(v.double().abs().sum() for v in sd_g.values())))})
+    print("wrote", out_path, len(t), "tensors;", len(feats), "garment features")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

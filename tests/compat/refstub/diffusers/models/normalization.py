@@ -1,0 +1,5 @@
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    from .. import _placeholder
+    return _placeholder(name)

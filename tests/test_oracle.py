@@ -159,3 +159,106 @@ def test_tiny_pipeline_regression_golden():
     img = opipe.run(o_t, o_g, o_v, Scheduler("ddpm"), num_inference_steps=4, guidance_scale=2.0, trace=tr, **inp)
     assert pu.relerr(tr["step_latents"][-1], t["latents_3"]) < 2e-3
     assert pu.relerr(img, t["image"]) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Oracle pinned to the REFERENCE'S OWN first-party code: tests/golden/reference_unet_tiny.safetensors holds outputs of
+# /root/reference/src/unet_hacked_{tryon,garmnet}.py, attentionhacked_*.py and ip_adapter/attention_processor.py executed
+# unmodified (oracle/make_golden_ref.py; only `diffusers` itself is the test-side stand-in tests/compat/refstub).
+# ------------------------------------------------------------------------------------------------------------------
+REF_TINY = dict(block_out_channels=(64, 128, 256), transformer_layers_per_block=(1, 1, 2), num_attention_heads=(1, 2, 4),
+                cross_attention_dim=128, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32,
+                encoder_hid_dim=128, resampler=dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, ff_mult=4))
+PIN_TOL = 2e-5          # fp32 vs fp32, different (equivalent) op order: e.g. softmax written out vs F.scaled_dot_product_attention
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def _oracle_pair():
+    import dataclasses
+    from idm_vton_amd import config as pc
+    from oracle import unet as ou
+    tcfg = pc.UNetConfig(mode="tryon", in_channels=13, **REF_TINY)
+    gcfg = pc.UNetConfig(mode="garmnet", in_channels=4, addition_embed_type=None, encoder_hid_dim_type=None, **REF_TINY)
+    as_o = lambda c: ou.UNetConfig(**{f.name: getattr(c, f.name) for f in dataclasses.fields(ou.UNetConfig)})
+    o_t, o_g = ou.UNet2DConditionModel(as_o(tcfg)).eval(), ou.UNet2DConditionModel(as_o(gcfg)).eval()
+    sd_t = pc.random_state_dict(pc.unet_param_shapes(tcfg), 101, torch.float32, "cpu")
+    sd_g = pc.random_state_dict(pc.unet_param_shapes(gcfg), 102, torch.float32, "cpu")
+    o_t.load_state_dict(sd_t)
+    o_g.load_state_dict(sd_g)
+    return o_t, o_g, sd_t, sd_g
+
+
+def _check_against_reference_fixture(t, meta):
+    o_t, o_g, sd_t, sd_g = _oracle_pair()
+    # same weights as the reference run (seeded generator; the sums are stored with the fixture)
+    assert abs(float(sum(v.double().abs().sum() for v in sd_t.values())) - float(meta["wsum_t"])) < 1e-6 * float(meta["wsum_t"])
+    assert abs(float(sum(v.double().abs().sum() for v in sd_g.values())) - float(meta["wsum_g"])) < 1e-6 * float(meta["wsum_g"])
+    with torch.no_grad():
+        # GarmentNet (src/unet_hacked_garmnet.py:917-1284): every exported norm1 output, in order
+        _, feats = o_g(t["garm.cloth_lat"], 481, t["garm.cloth_text"])
+        assert len(feats) == int(meta["n_garm_feats"]) == 17
+        for i, f in enumerate(feats):
+            assert _rel(f, t[f"garm.feat{i:02d}"]) <= PIN_TOL, (i, _rel(f, t[f"garm.feat{i:02d}"]))
+        # Resampler as the UNet's encoder_hid_proj (tryon_pipeline.py:1726)
+        ie = o_t.encoder_hid_proj(t["tryon.ip_states"])
+        assert _rel(ie, t["tryon.image_embeds"]) <= PIN_TOL
+        # TryonNet (src/unet_hacked_tryon.py:1006-1395) on the reference's own features, zero half materialised (:1796)
+        B2 = t["tryon.lmi"].shape[0]
+        time_ids = torch.tensor([[128, 128, 0, 0, 128, 128]], dtype=torch.float32).repeat(B2, 1)
+        feats_cfg = [torch.cat([torch.zeros_like(t[f"garm.feat{i:02d}"]), t[f"garm.feat{i:02d}"]]) for i in range(17)]
+        eps = o_t(t["tryon.lmi"], 481, t["tryon.pe"], added_cond_kwargs=dict(text_embeds=t["tryon.add_text"], time_ids=time_ids,
+                  image_embeds=t["tryon.image_embeds"]), garment_features=feats_cfg)[0]
+        assert _rel(eps, t["tryon.eps"]) <= PIN_TOL, _rel(eps, t["tryon.eps"])
+
+
+def _check_blocks_against_reference_fixture(t):
+    from oracle.unet import BasicTransformerBlock
+    dim, heads, hd, xd = 64, 1, 64, 64
+    with torch.no_grad():
+        bt = BasicTransformerBlock(dim, heads, hd, xd, "tryon", 16).eval()
+        bt.load_state_dict({k[len("blk_t.sd."):]: v for k, v in t.items() if k.startswith("blk_t.sd.")})     # strict: same keys
+        y, idx, _ = bt(t["blk.x"], t["blk.enc_t"], [t["blk.garm"]], 0)
+        assert idx == 1 and _rel(y, t["blk_t.y"]) <= PIN_TOL, _rel(y, t["blk_t.y"])
+        bg = BasicTransformerBlock(dim, heads, hd, xd, "garmnet", 16).eval()
+        bg.load_state_dict({k[len("blk_g.sd."):]: v for k, v in t.items() if k.startswith("blk_g.sd.")})
+        y, _, feat = bg(t["blk.x"], t["blk.enc_g"])
+        assert _rel(y, t["blk_g.y"]) <= PIN_TOL and torch.equal(feat, t["blk_g.feat"])
+        # the two processors on their own (ip_adapter/attention_processor.py:203-278, :1907-2010) inside the block's modules
+        a2 = bt.attn2
+        n2 = bt.norm2(t["blk.x"])
+        ref_like = a2(n2, encoder_hidden_states=t["blk.enc_t"])
+        q = a2.to_q(n2)
+        text, ip = t["blk.enc_t"][:, :77], t["blk.enc_t"][:, 77:]
+        man = (torch.softmax(q @ a2.to_k(text).transpose(1, 2) / 8.0, -1) @ a2.to_v(text)
+               + torch.softmax(q @ a2.processor.to_k_ip(ip).transpose(1, 2) / 8.0, -1) @ a2.processor.to_v_ip(ip))
+        assert _rel(ref_like, a2.to_out[0](man)) <= PIN_TOL
+
+
+def test_oracle_unets_match_reference_code_golden():
+    """oracle TryonNet / GarmentNet == the reference's own UNet2DConditionModel forwards (committed fixture)."""
+    t, meta = _load("reference_unet_tiny.safetensors")
+    _check_against_reference_fixture(t, meta)
+
+
+def test_oracle_blocks_match_reference_code_golden():
+    """oracle BasicTransformerBlock (tryon: garment concat + IP cross-attention; garmnet: norm1 export) and the attention
+    processors == the reference's own classes (committed fixture)."""
+    t, _ = _load("reference_unet_tiny.safetensors")
+    _check_blocks_against_reference_fixture(t)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/unet_hacked_tryon.py"), reason="reference checkout not present (GPU box)")
+def test_reference_code_golden_is_fresh(tmp_path):
+    """Re-run the reference's code here (subprocess: oracle/make_golden_ref.py) and compare with the committed fixture, so the
+    fixture cannot drift from /root/reference or from tests/compat/refstub."""
+    from oracle import make_golden as mg
+    out = mg.reference_unet_fixture(str(tmp_path / "fresh.safetensors"))
+    with safe_open(out, "pt") as f:
+        fresh = {k: f.get_tensor(k) for k in f.keys()}
+    t, _ = _load("reference_unet_tiny.safetensors")
+    assert fresh.keys() == t.keys()
+    for k in t:
+        assert torch.equal(fresh[k], t[k]), k
