@@ -23,6 +23,26 @@ def preprocess_mask(mask):
 
 
 @torch.no_grad()
+def denoise(unet, unet_encoder, sched, timesteps, latents, mask_l, masked_lat, pose_lat, cloth_lat, pe, added,
+            text_embeds_cloth, guidance_scale, noise_steps=None, trace=None):
+    """The loop body of `__call__` (src/tryon_pipeline.py:1764-1866) from prepared conditioning: mask_l / masked_lat / pose_lat
+    [2B,*,h,w] (both CFG halves), cloth_lat [B,4,h,w], pe [2B,77,D], added = {text_embeds, time_ids, image_embeds}."""
+    for i, t in enumerate(timesteps):                                                   # :1765
+        lmi = torch.cat([latents] * 2)                                                  # :1769 (scale_model_input = id)
+        lmi = torch.cat([lmi, mask_l, masked_lat, pose_lat], dim=1)                     # :1777
+        _, feats = unet_encoder(cloth_lat, t, text_embeds_cloth)                        # :1787
+        feats = [torch.cat([torch.zeros_like(d), d]) for d in feats]                    # :1796
+        eps = unet(lmi, t, pe, added_cond_kwargs=added, garment_features=feats)[0]      # :1799-1808
+        eu, et = eps.chunk(2)                                                           # :1815
+        eps = eu + guidance_scale * (et - eu)                                           # :1816
+        latents = sched.step(eps, t, latents, noise_steps[i] if noise_steps is not None else None)  # :1823
+        if trace is not None:
+            trace["step_eps"].append(eps.clone())
+            trace["step_latents"].append(latents.clone())
+    return latents
+
+
+@torch.no_grad()
 def run(unet, unet_encoder, vae, sched, *, image, mask_image, pose_img, cloth, prompt_embeds, negative_prompt_embeds,
         pooled_prompt_embeds, negative_pooled_prompt_embeds, text_embeds_cloth, ip_hidden_states, noise,
         num_inference_steps=30, guidance_scale=2.0, height=None, width=None, return_latents=False, trace=None):
@@ -59,18 +79,8 @@ def run(unet, unet_encoder, vae, sched, *, image, mask_image, pose_img, cloth, p
         trace.update(masked_lat=masked_lat, pose_lat=pose_lat, cloth_lat=cloth_lat, image_embeds=image_embeds,
                      mask_l=mask_l, latents0=latents.clone(), step_latents=[], step_eps=[])
 
-    for i, t in enumerate(timesteps):                                                   # :1765
-        lmi = torch.cat([latents] * 2)                                                  # :1769 (scale_model_input = id)
-        lmi = torch.cat([lmi, mask_l, masked_lat, pose_lat], dim=1)                     # :1777
-        _, feats = unet_encoder(cloth_lat, t, text_embeds_cloth)                        # :1787
-        feats = [torch.cat([torch.zeros_like(d), d]) for d in feats]                    # :1796
-        eps = unet(lmi, t, pe, added_cond_kwargs=added, garment_features=feats)[0]      # :1799-1808
-        eu, et = eps.chunk(2)                                                           # :1815
-        eps = eu + guidance_scale * (et - eu)                                           # :1816
-        latents = sched.step(eps, t, latents, noise["steps"][i] if noise.get("steps") is not None else None)  # :1823
-        if trace is not None:
-            trace["step_eps"].append(eps.clone())
-            trace["step_latents"].append(latents.clone())
+    latents = denoise(unet, unet_encoder, sched, timesteps, latents, mask_l, masked_lat, pose_lat, cloth_lat, pe, added,
+                      text_embeds_cloth, guidance_scale, noise.get("steps"), trace)
     if return_latents:
         return latents
     img = vae.decode(latents / sf)                                                      # :1876

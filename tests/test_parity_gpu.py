@@ -58,3 +58,15 @@ def test_serial_loop_is_bit_reproducible():
         st = eng.prepare(num_inference_steps=3, guidance_scale=2.0, scheduler="ddpm", **inp)
         outs.append(eng.denoise(st, use_graph=use_graph).clone())
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_mid_pipeline_parity(dtype):
+    """The wider configuration of tests/parity_utils.py (320/640/1280 channels, 5/10/20 heads: the SDXL widths, 128x128 GEMM
+    tiles, group size 10) through every stage against the oracle."""
+    from tests import parity_checks
+    r = parity_checks.run("mid", dtype, B=1, H=128, W=128, steps=2)
+    t = TOL[dtype]
+    for k in ("resampler", "vae_encode", "vae_decode", "garment_feat_max", "tryon_eps", "tryon_eps_materialised_zeros"):
+        assert r[k] <= t["stage"], (k, r)
+    assert r["latents_final"] <= t["latents"] and r["image"] <= t["image"], r
