@@ -38,7 +38,9 @@ class _SchedulerBase:
         if self._kind == "ddpm" and cfg["variance_type"] != "fixed_small":
             raise NotImplementedError("DDPM variance_type other than 'fixed_small'")
         self.config = SimpleNamespace(**cfg)
-        self._impl = StepScheduler(self._kind, cfg["num_train_timesteps"], cfg["beta_start"], cfg["beta_end"], cfg["steps_offset"])
+        self._impl = StepScheduler(self._kind, cfg["num_train_timesteps"], cfg["beta_start"], cfg["beta_end"], cfg["steps_offset"],
+                                   set_alpha_to_one=bool(kw.get("set_alpha_to_one", False)))
+        self.config.set_alpha_to_one = bool(kw.get("set_alpha_to_one", False))
         self.init_noise_sigma = 1.0
         self.order = 1
         self.timesteps = None

@@ -50,6 +50,20 @@ def _to_tensor_image(x, name, lo_hi=None):
     return x.float()
 
 
+def _randn(shape, generator, device, dtype):
+    """diffusers.utils.torch_utils.randn_tensor semantics, result as fp32 on `device`."""
+    dev = torch.device(device)
+    if isinstance(generator, (list, tuple)):
+        if len(generator) != shape[0]:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch size "
+                             f"of {shape[0]}. Make sure the batch size matches the length of the generators.")
+        return torch.cat([_randn((1,) + tuple(shape[1:]), g, device, dtype) for g in generator], dim=0)
+    rand_device = dev
+    if generator is not None and generator.device.type != dev.type and generator.device.type == "cpu":
+        rand_device = torch.device("cpu")
+    return torch.randn(shape, generator=generator, device=rand_device, dtype=dtype).to(dev).float()
+
+
 class StableDiffusionXLInpaintPipeline:
     _optional_components = ["tokenizer", "tokenizer_2", "text_encoder", "text_encoder_2", "image_encoder",
                             "feature_extractor", "unet_encoder"]
@@ -339,13 +353,17 @@ class StableDiffusionXLInpaintPipeline:
 
         # RNG consumption order of the reference: latents, masked-image posterior, pose posterior (GLOBAL
         # generator: tryon_pipeline.py:1646 passes none), cloth posterior, then one draw per DDPM step with t > 0
+        # Each draw mirrors diffusers' randn_tensor as the reference calls it: on the GENERATOR's device (a CPU generator draws
+        # on the CPU and the result is moved; a list of generators draws per sample) and in the dtype the reference draws in --
+        # initial latents: prompt_embeds.dtype (:1599-1610 -> prepare_latents :889); VAE posterior samples: fp32, the VAE being
+        # upcast (:913-915, DiagonalGaussianDistribution.sample); DDPM variance noise: the model output's dtype (DDPMScheduler.step).
         shape = (B, 4, h, w)
-        draw = lambda gen: torch.randn(shape, generator=gen, device=device, dtype=eng.dtype).float()
-        n_lat = latents.to(device).float() if latents is not None else draw(generator)
-        n_masked, n_pose, n_cloth = draw(generator), draw(None), draw(generator)
+        n_lat = latents.to(device).float() if latents is not None else _randn(shape, generator, device, prompt_embeds.dtype)
+        n_masked, n_pose, n_cloth = (_randn(shape, generator, device, torch.float32), _randn(shape, None, device, torch.float32),
+                                     _randn(shape, generator, device, torch.float32))
         steps_noise = None
         if kind == "ddpm":
-            steps_noise = torch.stack([draw(generator) for _ in range(num_inference_steps)])
+            steps_noise = torch.stack([_randn(shape, generator, device, eng.dtype) for _ in range(num_inference_steps)])
         image_states = self.prepare_ip_adapter_image_embeds(ip_adapter_image, device, 1)        # :1720-1723
 
         lat = eng(image=img, mask_image=msk, pose_img=pose, cloth=clo, prompt_embeds=prompt_embeds,

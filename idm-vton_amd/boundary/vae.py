@@ -83,10 +83,14 @@ class AutoencoderKL(nn.Module):
         p0 = next(self.parameters())
         if not p0.is_cuda:
             raise RuntimeError("AutoencoderKL runs on the GPU only (HIP kernels); call .to('cuda') first")
-        # the reference upcasts the VAE to fp32 for decoding (tryon_pipeline.py:1868-1880); the HIP VAE keeps fp32
-        # accumulation / fp32 GroupNorm statistics and bf16 storage instead, so an fp32 module is run
-        # with bf16 storage rather than refused
-        dt = p0.dtype if p0.dtype in (torch.float16, torch.bfloat16) else torch.bfloat16
+        # The reference runs the VAE in fp32 whenever the module is fp16 and config.force_upcast is set (upcast_vae,
+        # tryon_pipeline.py:911-930, 1868-1880): the SDXL VAE's activations overflow fp16.  The HIP VAE has fp32 accumulation,
+        # fp32 GroupNorm statistics and an fp32 softmax; what it stores between layers is 16-bit, so the storage type must have
+        # fp32's EXPONENT range: an fp16 (or fp32) module is executed with bf16 storage (same MFMA rate), never with fp16
+        # storage, unless force_upcast is explicitly False (the fp16-fix VAE checkpoints set that).
+        dt = p0.dtype
+        if dt not in (torch.float16, torch.bfloat16) or (dt == torch.float16 and getattr(self.config, "force_upcast", True)):
+            dt = torch.bfloat16
         key = (params_version(self), dt)
         if key != self._hip_key:
             self._hip = HipVAE(self.cfg, self.state_dict(), dt, p0.device)

@@ -9,13 +9,18 @@ import numpy as np
 
 
 class StepScheduler:
-    def __init__(self, kind="ddpm", num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+    def __init__(self, kind="ddpm", num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 set_alpha_to_one=False):
         if kind not in ("ddpm", "ddim"):
             raise ValueError(f"unknown scheduler kind {kind!r}")
         self.kind, self.T, self.steps_offset = kind, num_train_timesteps, steps_offset
         import torch                      # same float32 linspace / cumprod ops as diffusers' DDPMScheduler.__init__
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).double().numpy()
+        # diffusers DDIMScheduler.final_alpha_cumprod: alphas_cumprod[0] unless set_alpha_to_one (SDXL scheduler_config: false);
+        # used for the step whose previous timestep is < 0 (leading spacing + steps_offset=1: the LAST step, t = 1).
+        # DDPMScheduler has no such switch: its previous alpha-bar is 1 there.
+        self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])
         self.init_noise_sigma = 1.0
         self.order = 1
 
@@ -30,7 +35,7 @@ class StepScheduler:
         t = int(t)
         prev_t = t - self.T // self.n
         ab_t = float(self.alphas_cumprod[t])
-        ab_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        ab_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else (1.0 if self.kind == "ddpm" else self.final_alpha_cumprod)
         bb_t, bb_p = 1.0 - ab_t, 1.0 - ab_p
         if self.kind == "ddpm":
             a_t = ab_t / ab_p

@@ -55,6 +55,7 @@ class HipUNet:
         for h, c in zip(cfg.num_attention_heads, cfg.block_out_channels):
             assert c % 64 == 0 and (c // h == 64), "HIP attention kernels are specialised for head_dim 64"
         self.tryon = cfg.mode == "tryon"
+        self.ip_scale = 1.0                              # IPAttnProcessor2_0.scale (ip_adapter/attention_processor.py:1995): hidden = text + scale * ip
         self.cin_pad = _pad64(cfg.in_channels)
         self._prep()
         self._gn_stats = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=self.device)
@@ -248,7 +249,7 @@ class HipUNet:
         seg_t = dict(k=kv["kt"], vt=kv["vtt"], nk=ctx["nt"], ldk=C, ldvt=ctx["rt"], k_rows=ctx["rt"])
         if self.tryon:
             seg_i = dict(k=kv["ki"], vt=kv["vti"], nk=ctx["ni"], ldk=C, ldvt=ctx["ri"], k_rows=ctx["ri"])
-            ops.attention(q2, att2, [seg_t, seg_i], heads, mode=ffi.ATTN_CROSS, ip_scale=1.0, B=B, Nq=N, ldq=C, ldo=C)
+            ops.attention(q2, att2, [seg_t, seg_i], heads, mode=ffi.ATTN_CROSS, ip_scale=self.ip_scale, B=B, Nq=N, ldq=C, ldo=C)
         else:
             ops.attention(q2, att2, [seg_t], heads, B=B, Nq=N, ldq=C, ldo=C)
         hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs)

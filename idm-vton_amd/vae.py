@@ -99,14 +99,16 @@ class HipVAE:
     def _attn(self, p, x, B, N, C):
         sd, dt, dev = self.sd, self.dtype, self.device
         t = self._gn(x, p + ".group_norm", False).reshape(B * N, C)
-        q = ops.linear(t, sd[p + ".to_q.weight"], bias=sd[p + ".to_q.bias"])
+        # q leaves its projection multiplied by C^-0.5 (fp32, before the one rounding): the N x N scores stored between the two
+        # GEMMs are then softmax logits of O(1) magnitude instead of raw 512-term dot products
+        q = ops.linear(t, sd[p + ".to_q.weight"], bias=sd[p + ".to_q.bias"], colscale_n=C, colscale=C ** -0.5)
         k = ops.linear(t, sd[p + ".to_k.weight"], bias=sd[p + ".to_k.bias"])
         vt = torch.empty(B, C, N, dtype=dt, device=dev)
         ops.linear(t, sd[p + ".to_v.weight"], bias=sd[p + ".to_v.bias"], vt=vt, vt_n0=0, vt_tokens=N, vt_perm=False)
         o = torch.empty(B * N, C, dtype=dt, device=dev)
         for b in range(B):
             s = ops.linear(q[b * N:(b + 1) * N], k[b * N:(b + 1) * N])          # [N][N] scores
-            ops.softmax_rows(s, C ** -0.5)
+            ops.softmax_rows(s, 1.0)
             ops.linear(s, vt[b], out=o[b * N:(b + 1) * N])
         out = ops.linear(o, sd[p + ".to_out.0.weight"], bias=sd[p + ".to_out.0.bias"], res=x.reshape(B * N, C))
         return out.view(B, N, C)

@@ -136,6 +136,30 @@ def test_scheduler_timesteps_and_final_step():
     assert torch.allclose(d.step(e, 958, x), ab_p ** 0.5 * x0 + (1 - ab_p) ** 0.5 * e, atol=1e-6)
 
 
+def test_ddim_last_step_uses_final_alpha_cumprod():
+    """diffusers DDIMScheduler: the step whose previous timestep is < 0 (leading spacing, steps_offset 1: t = 1) uses
+    final_alpha_cumprod = alphas_cumprod[0] when set_alpha_to_one is false (the SDXL scheduler_config value), 1.0 when true;
+    DDPMScheduler always uses 1.0 there.  alphas_cumprod[0] = 1 - beta_start = 0.99915 for scaled_linear 0.00085..0.012."""
+    from idm_vton_amd.scheduler import StepScheduler
+    for cls in (Scheduler, StepScheduler):
+        d = cls("ddim")
+        ts = d.set_timesteps(30)
+        assert int(ts[-1]) == 1 and abs(float(d.alphas_cumprod[0]) - 0.99915) < 1e-6
+        ab_t, ab_p = float(d.alphas_cumprod[1]), float(d.alphas_cumprod[0])
+        c = d.coeffs(1)
+        c_x, c_eps = (c[1], c[0]) if cls is Scheduler else (c[0], c[1])
+        assert abs(c_x - (ab_p / ab_t) ** 0.5) < 1e-9
+        assert abs(c_eps - ((1 - ab_p) ** 0.5 - (ab_p * (1 - ab_t) / ab_t) ** 0.5)) < 1e-9
+        one = cls("ddim", set_alpha_to_one=True)
+        one.set_timesteps(30)
+        c1 = one.coeffs(1)
+        assert abs((c1[1] if cls is Scheduler else c1[0]) - (1.0 / ab_t) ** 0.5) < 1e-9
+        p = cls("ddpm")
+        p.set_timesteps(30)
+        cp = p.coeffs(1)                                    # DDPM at t=1: x_prev = x0 exactly (previous alpha-bar 1), sigma from the clamp
+        assert abs((cp[1] if cls is Scheduler else cp[0]) - (1.0 / ab_t) ** 0.5) < 1e-6
+
+
 def test_product_scheduler_matches_oracle_scheduler():
     from idm_vton_amd.scheduler import StepScheduler
     for kind in ("ddpm", "ddim"):
