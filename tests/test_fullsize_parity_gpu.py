@@ -27,8 +27,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 H, W = 1024, 768
-BARS = {torch.float16: dict(garment_feat_max=3e-3, tryon_eps=4e-3, latents_step=4e-3, vae_decode=6e-3, garment_feat_max_cfg4=3e-3),
-        torch.bfloat16: dict(garment_feat_max=2.5e-2, tryon_eps=3e-2, latents_step=3e-2, vae_decode=5e-2, garment_feat_max_cfg4=2.5e-2)}
+BARS = {torch.float16: dict(garment_feat_max=5e-3, tryon_eps=6e-3, latents_step=6e-3, vae_decode=8e-3, garment_feat_max_cfg4=5e-3),
+        torch.bfloat16: dict(garment_feat_max=3.5e-2, tryon_eps=4e-2, latents_step=4e-2, vae_decode=6e-2, garment_feat_max_cfg4=3.5e-2)}
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
