@@ -1,0 +1,12 @@
+import numpy as np
+import torch
+
+
+def save_image(tensor, fp, **kwargs):
+    """A CxHxW (or 1xCxHxW) float tensor in [0, 1] -> image file (torchvision.utils.save_image for a single image)."""
+    from PIL import Image
+    t = tensor.detach().float().cpu()
+    if t.ndim == 4:
+        t = t[0]
+    a = t.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(a[:, :, 0] if a.shape[2] == 1 else a).save(fp)
