@@ -47,10 +47,9 @@ def main():
     for name, eng in (("bf16", eng_bf), ("f16", eng_fp)):
         st = eng.prepare(num_inference_steps=steps, guidance_scale=2.0, scheduler="ddim", **inp)
         if st0 is None:
-            st0 = st
+            st0, lat_start = st, st["latents"].clone()   # (denoise() updates st["latents"] in place)
         else:                                            # same prepared conditioning for both storage dtypes (values are bf16-exact)
-            for k in ("latents",):
-                st[k].copy_(st0[k])
+            st["latents"].copy_(lat_start)
             st["cond"].copy_(st0["cond"].to(st["cond"].dtype))
             st["cloth"].copy_(st0["cloth"].to(st["cloth"].dtype))
             st["ctx_t"] = eng.unet.encode_context(torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]]), st0["trace"]["image_embeds"].float())
