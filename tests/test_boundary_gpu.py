@@ -148,9 +148,11 @@ def test_pipeline_boundary_end_to_end():
     eng = pipe.hip_engine()
     gen = torch.Generator(DEV).manual_seed(7)
     torch.manual_seed(123)
-    draw = lambda gg: torch.randn((B, 4, H // 8, W // 8), generator=gg, device=DEV, dtype=DT).float()
-    n_lat, n_masked, n_pose, n_cloth = draw(gen), draw(gen), draw(None), draw(gen)
-    n_steps = torch.stack([draw(gen) for _ in range(steps)])
+    # dtypes as the reference draws them (randn_tensor): latents in the prompt dtype, VAE posterior samples in fp32 (upcast VAE),
+    # DDPM variance noise in the model-output dtype
+    draw = lambda gg, dt_: torch.randn((B, 4, H // 8, W // 8), generator=gg, device=DEV, dtype=dt_).float()
+    n_lat, n_masked, n_pose, n_cloth = draw(gen, DT), draw(gen, torch.float32), draw(None, torch.float32), draw(gen, torch.float32)
+    n_steps = torch.stack([draw(gen, DT) for _ in range(steps)])
     with torch.no_grad():
         pos = enc(clip_pix.to(DEV, DT), output_hidden_states=True).hidden_states[-2]
         neg = enc(torch.zeros_like(clip_pix).to(DEV, DT), output_hidden_states=True).hidden_states[-2]
@@ -173,3 +175,15 @@ def test_pipeline_boundary_end_to_end():
     assert out.shape == (B, 4, 16, 16) and torch.isfinite(out).all()
     with pytest.raises(ValueError, match="text_embeds"):
         t(torch.randn(B, 13, 16, 16, device=DEV, dtype=DT), 481, inp["prompt_embeds"].to(DEV), added_cond_kwargs={}, garment_features=feats)
+    # IPAttnProcessor2_0.scale is honoured by the fused forward (hidden = text + scale * ip, attention_processor.py:1995):
+    # with scale 0 the image tokens have no effect at all, with scale 1 they do
+    x13 = torch.randn(B, 13, 16, 16, device=DEV, dtype=DT)
+    other = dict(added, image_embeds=torch.randn(B, 16, kw["cross_attention_dim"], device=DEV, dtype=DT))
+    run = lambda ad: t(x13, 481, inp["prompt_embeds"].to(DEV), added_cond_kwargs=ad, garment_features=feats, return_dict=False)[0]
+    base1, alt1 = run(added), run(other)
+    assert not torch.equal(base1, alt1)
+    for proc in t.attn_processors.values():
+        if hasattr(proc, "to_k_ip"):
+            proc.scale = 0.0
+    base0, alt0 = run(added), run(other)
+    assert torch.equal(base0, alt0) and not torch.equal(base0, base1)
