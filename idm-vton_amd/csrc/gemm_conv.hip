@@ -353,7 +353,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 //    LDS rate, ~10-12 TB/s with all 256 CUs streaming, so a launch's ceiling is its tile's arithmetic intensity times that.
 //    A third: every launch touching the NEXT launch's weights (one dword per line, LDS-DMA into scratch) so they are cache
 //    resident at its start -- -10..-32 % per launch in isolation behind a cache flush, +-0 in the pipeline (GEMM time per
-//    denoising step 46.6 vs 46.3 ms, profiles/r02_bench_prefetch_ab.txt): removed.)
+//    denoising step 46.6 vs 46.3 ms, profiles/r02_bench_prefetch_ab.txt): removed.  A fourth: the next tile's DMA front-loaded
+//    into the first one or two k-steps of the 8-wave tiles instead of spread over all four: -3..+3 %
+//    (profiles/r02_probe_gemm_v4.log): removed.)
 //   v2                : the v1 tiles (except 128x128, which already has it) with the fragments of k-step s+1 read from LDS
 //                       ahead of the MFMAs of step s (PMC: 45 % of wave cycles of the 8-wave tiles sit in s_waitcnt, mostly
 //                       lgkmcnt in front of each k-step; both waves of a SIMD are barrier-aligned so neither covers the other)

@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--test_batch_size", type=int, default=2)
     ap.add_argument("--dump_latents", default=None, help="(test hook) also save pipe(..., output_type='latent') of the first batch")
     a = ap.parse_args()
+    from accelerate.utils import set_seed
+    set_seed(a.seed)                                     # inference.py:214-215: the pose posterior is drawn from the GLOBAL generator
     P, dev = a.pretrained_model_name_or_path, torch.device("cuda" if torch.cuda.is_available() else "cpu")
     os.makedirs(a.output_dir, exist_ok=True)
     noise_scheduler = DDPMScheduler.from_pretrained(P, subfolder="scheduler")
