@@ -24,14 +24,20 @@ runs the reference's OWN first-party code with a test-only stand-in for the thir
       - oracle/layers.py AttnProcessor2_0 / IPAttnProcessor2_0 == /root/reference/ip_adapter/attention_processor.py
       - state-dict keys and shapes (idm-vton_amd/config.py inventory): loaded with strict=True into the
         reference's UNet2DConditionModel classes
+      - oracle/pipeline.py  the whole `__call__` == the reference's StableDiffusionXLInpaintPipeline.__call__
+                         (/root/reference/src/tryon_pipeline.py:1254-1894) run on the reference's own UNets: argument handling, image /
+                         mask preprocessing, prepare_latents / prepare_mask_latents, pose / cloth conditioning, time ids, the loop body,
+                         CFG, decode + postprocess, and the ORDER of the random draws -- per-step latents and final image
+                         within 2e-5 (the two diffusers components it calls, AutoencoderKL and DDPMScheduler, are adapters over
+                         oracle/vae.py and oracle/scheduler.py on both sides)
       - oracle/resampler.py bit-equal to /root/reference/ip_adapter/resampler.py (tests/golden/resampler_ref.safetensors)
     The third-party LAYERS those files call (diffusers Attention, ResnetBlock2D, Down/Upsample2D, GEGLU, Timesteps,
     TimestepEmbedding) are supplied by tests/compat/refstub, written from that release's published semantics -- their
     source is not under /root/reference, so for them the pin is to an independent restatement, not to diffusers itself.
-  * UNPINNED ("parity unpinned"): oracle/vae.py (diffusers AutoencoderKL), oracle/scheduler.py (diffusers DDPM/DDIM step) and
-    the pipeline loop arithmetic of oracle/pipeline.py (src/tryon_pipeline.py imports the diffusers pipeline machinery
-    wholesale) -- restated from the cited lines and SURVEY.md Appendix B, self-checked by closed-form schedule values and
-    identities, not by outputs of the reference itself.
+  * UNPINNED ("parity unpinned"): oracle/vae.py (diffusers AutoencoderKL) and oracle/scheduler.py (diffusers DDPM / DDIM step):
+    pure third-party arithmetic whose source is not under /root/reference -- restated from SURVEY.md Appendix B, self-checked by
+    closed-form schedule values (alphas_cumprod[0] = 0.99915, the DDIM / DDPM identities of tests/test_oracle.py), not by outputs
+    of diffusers itself.
 
 Every function cites the reference file:line it follows.
 """

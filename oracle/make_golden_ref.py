@@ -62,6 +62,130 @@ def ref_unet_kwargs(cfg):
     return kw
 
 
+def _load_pkg(name, d):
+    """Import the package at directory `d` under `name` without putting its parent on sys.path."""
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, "__init__.py"), submodule_search_locations=[d])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+@torch.no_grad()
+def pipeline_fixture(t, pc, ref_t, ref_g):
+    """The reference's OWN `StableDiffusionXLInpaintPipeline.__call__` (src/tryon_pipeline.py:1254-1894) driving the reference's own
+    UNets for 3 DDPM steps at 64x64 -- its argument handling, image / mask preprocessing, prepare_latents / prepare_mask_latents,
+    the three VAE encodes, pose / cloth conditioning, added time ids, IP-Adapter path, loop body, CFG, scheduler call, decode and
+    postprocess -- with the two diffusers components it calls into (AutoencoderKL, DDPMScheduler) adapted from oracle/vae.py and
+    oracle/scheduler.py (so both sides of the later comparison share those restatements and the comparison isolates the pipeline
+    code).  Every random draw is recorded in order (the order itself is part of what is pinned: SURVEY.md A.4)."""
+    from types import SimpleNamespace
+    import diffusers.utils.torch_utils as tu
+    from src.tryon_pipeline import StableDiffusionXLInpaintPipeline as RefPipe
+    _load_pkg("oracle", os.path.join(ROOT, "oracle"))
+    from oracle.scheduler import Scheduler
+    from oracle.vae import AutoencoderKL as OVae, VAEConfig as OVaeCfg
+    vcfg = pc.VAEConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    o_v = OVae(OVaeCfg(**{f: getattr(vcfg, f) for f in OVaeCfg.__dataclass_fields__})).eval()
+    o_v.load_state_dict(pc.random_state_dict(pc.vae_param_shapes(vcfg), 103, torch.float32, "cpu", std=0.05))
+
+    class Dist:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def sample(self, generator=None):
+            return self.mean + self.std * tu.randn_tensor(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+
+    class VaeAdapter(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = o_v
+            self.config = SimpleNamespace(scaling_factor=vcfg.scaling_factor, block_out_channels=vcfg.block_out_channels,
+                                          force_upcast=False, latent_channels=4)
+
+        @property
+        def dtype(self):
+            return torch.float32
+
+        def encode(self, x):
+            mean, std = self.m.encode_moments(x)
+            return SimpleNamespace(latent_dist=Dist(mean, std))
+
+        def decode(self, z, return_dict=True):
+            return (self.m.decode(z),)
+
+    class SchedAdapter:
+        order, init_noise_sigma = 1, 1.0
+
+        def __init__(self):
+            self.s = Scheduler("ddpm")
+            self.config = SimpleNamespace(num_train_timesteps=1000)
+
+        def set_timesteps(self, n, device=None):
+            self.timesteps = self.s.set_timesteps(n)
+
+        def scale_model_input(self, sample, timestep=None):
+            return sample
+
+        def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+            noise = None
+            if int(timestep) > 0:                        # diffusers DDPMScheduler.step: variance noise drawn only for t > 0
+                noise = tu.randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+            return (self.s.step(model_output, timestep, sample, noise),)
+
+    class FakeCLIPVision(torch.nn.Module):
+        """Deterministic stand-in for CLIPVisionModelWithProjection (the CLIP towers are outside the pinned path)."""
+
+        def __init__(self, dim):
+            super().__init__()
+            g = torch.Generator().manual_seed(55)
+            self.w = torch.nn.Parameter(torch.randn(3, dim, generator=g) * 0.5, requires_grad=False)
+
+        def forward(self, pixel_values, output_hidden_states=False):
+            p = torch.nn.functional.adaptive_avg_pool2d(pixel_values.float(), (16, 16)).flatten(2).transpose(1, 2)
+            h = torch.cat([p.mean(1, keepdim=True), p], dim=1) @ self.w
+            return SimpleNamespace(hidden_states=[h * 0.5, h, h * 2.0], image_embeds=h[:, 0])
+
+    enc = FakeCLIPVision(128)
+    pipe = RefPipe(vae=VaeAdapter(), text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=ref_t,
+                   unet_encoder=ref_g, scheduler=SchedAdapter(), image_encoder=enc, feature_extractor=None)
+    g = torch.Generator().manual_seed(31337)
+    r = lambda *s: torch.randn(*s, generator=g)
+    B, H, W, steps = 1, 64, 64, 3
+    mask = torch.zeros(B, 1, H, W)
+    mask[:, :, 16:48, 16:48] = 1
+    inp = dict(image=torch.rand(B, 3, H, W, generator=g), mask_image=mask, pose_img=r(B, 3, H, W).clamp(-1, 1), cloth=r(B, 3, H, W).clamp(-1, 1),
+               prompt_embeds=r(B, 77, 128), negative_prompt_embeds=r(B, 77, 128), pooled_prompt_embeds=r(B, 64),
+               negative_pooled_prompt_embeds=r(B, 64), text_embeds_cloth=r(B, 77, 128), clip_pixels=r(B, 3, 224, 224))
+    tu.RECORD = []
+    torch.manual_seed(4242)                               # the pose posterior is drawn from the GLOBAL generator (:1646)
+    step_lat = []
+    orig_step = pipe.scheduler.step
+
+    def rec_step(*a, **k):
+        out = orig_step(*a, **k)
+        step_lat.append(out[0].clone())
+        return out
+    pipe.scheduler.step = rec_step
+    images = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                  pooled_prompt_embeds=inp["pooled_prompt_embeds"], negative_pooled_prompt_embeds=inp["negative_pooled_prompt_embeds"],
+                  num_inference_steps=steps, generator=torch.Generator().manual_seed(7), strength=1.0, pose_img=inp["pose_img"],
+                  text_embeds_cloth=inp["text_embeds_cloth"], cloth=inp["cloth"], mask_image=inp["mask_image"], image=inp["image"],
+                  height=H, width=W, guidance_scale=2.0, ip_adapter_image=inp["clip_pixels"], output_type="pt")[0]
+    draws, tu.RECORD = tu.RECORD, None
+    assert len(draws) == 4 + (steps - 1) or len(draws) == 4 + steps, len(draws)
+    for k, v in inp.items():
+        t[f"pipe.in.{k}"] = v
+    for i, d in enumerate(draws):
+        t[f"pipe.draw{i}"] = d
+    for i, l in enumerate(step_lat):
+        t[f"pipe.latents{i}"] = l
+    t["pipe.image"] = images
+    pos = enc(inp["clip_pixels"], output_hidden_states=True).hidden_states[-2]
+    neg = enc(torch.zeros_like(inp["clip_pixels"]), output_hidden_states=True).hidden_states[-2]
+    t["pipe.ip_hidden_states"] = torch.cat([neg, pos])
+
+
 @torch.no_grad()
 def main(out_path):
     from src.unet_hacked_tryon import UNet2DConditionModel as RefTryon
@@ -119,6 +243,8 @@ def main(out_path):
     y_g, exported = bg(x, encoder_hidden_states=enc_g)
     t.update({"blk.x": x, "blk.garm": garm, "blk.enc_t": enc_t, "blk.enc_g": enc_g, "blk_t.y": y_t, "blk_g.y": y_g,
               "blk_g.feat": exported[0]})
+
+    pipeline_fixture(t, pc, ref_t, ref_g)
 
     save_file({k: v.contiguous() for k, v in t.items()}, out_path,
               metadata={"generator": "oracle/make_golden_ref.py", "reference": REF, "n_garm_feats": str(len(feats)),

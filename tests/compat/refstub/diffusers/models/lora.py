@@ -27,3 +27,7 @@ class LoRALinearLayer(nn.Module):
 
 class LoRAConv2dLayer(LoRALinearLayer):
     pass
+
+
+def adjust_lora_scale_text_encoder(text_encoder, lora_scale: float = 1.0):
+    raise NotImplementedError("LoRA is not on the IDM-VTON inference path")

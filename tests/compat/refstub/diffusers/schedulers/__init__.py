@@ -1,4 +1,5 @@
-from .embeddings import ImageProjection  # noqa: F401  (isinstance check at src/tryon_pipeline.py:493)
+class KarrasDiffusionSchedulers:
+    pass
 
 
 def __getattr__(name):

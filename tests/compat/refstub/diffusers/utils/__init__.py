@@ -36,6 +36,20 @@ def is_torch_version(op, version):
             "<=": cur <= V.parse(version), "==": cur == V.parse(version)}[op]
 
 
+def is_invisible_watermark_available():
+    return False
+
+
+def is_torch_xla_available():
+    return False
+
+
+def replace_example_docstring(example_docstring):
+    def deco(fn):
+        return fn
+    return deco
+
+
 def scale_lora_layers(model, weight):
     return None
 

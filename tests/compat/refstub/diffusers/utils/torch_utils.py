@@ -9,8 +9,18 @@ def apply_freeu(resolution_idx, hidden_states, res_hidden_states, **freeu_kwargs
     raise NotImplementedError("FreeU is not on the IDM-VTON path")
 
 
+RECORD = None                                        # tests: a list that receives every draw, in order
+
+
 def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
     """diffusers.utils.torch_utils.randn_tensor: draws on the generator's device (CPU generator -> CPU draw, then moved)."""
+    out = _randn_tensor(shape, generator, device, dtype, layout)
+    if RECORD is not None:
+        RECORD.append(out.clone())
+    return out
+
+
+def _randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
     rand_device = device
     if generator is not None:
         gen_device_type = generator.device.type if not isinstance(generator, list) else generator[0].device.type

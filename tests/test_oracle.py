@@ -286,3 +286,34 @@ def test_reference_code_golden_is_fresh(tmp_path):
     assert fresh.keys() == t.keys()
     for k in t:
         assert torch.equal(fresh[k], t[k]), k
+
+
+def _check_pipeline_against_reference_fixture(t):
+    """oracle/pipeline.py:run == the reference's own StableDiffusionXLInpaintPipeline.__call__ (src/tryon_pipeline.py:1254-1894):
+    same UNet weights, the reference's recorded random draws fed in the order SURVEY.md A.4 states (initial latents, masked-image
+    posterior, pose posterior [global generator], cloth posterior, one DDPM draw per step with t > 0)."""
+    import dataclasses
+    from idm_vton_amd import config as pc
+    from oracle import pipeline as opipe
+    from oracle.vae import AutoencoderKL as OVae, VAEConfig as OVaeCfg
+    o_t, o_g, _, _ = _oracle_pair()
+    vcfg = pc.VAEConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    o_v = OVae(OVaeCfg(**{f.name: getattr(vcfg, f.name) for f in dataclasses.fields(OVaeCfg)})).eval()
+    o_v.load_state_dict(pc.random_state_dict(pc.vae_param_shapes(vcfg), 103, torch.float32, "cpu", std=0.05))
+    draws = [t[f"pipe.draw{i}"] for i in range(sum(k.startswith("pipe.draw") for k in t))]
+    n_steps = sum(k.startswith("pipe.latents") for k in t)
+    assert len(draws) == 4 + n_steps == 7
+    inp = {k[len("pipe.in."):]: v for k, v in t.items() if k.startswith("pipe.in.")}
+    inp.pop("clip_pixels")
+    tr = {}
+    img = opipe.run(o_t, o_g, o_v, Scheduler("ddpm"), num_inference_steps=n_steps, guidance_scale=2.0, trace=tr,
+                    ip_hidden_states=t["pipe.ip_hidden_states"],
+                    noise=dict(latents=draws[0], masked=draws[1], pose=draws[2], cloth=draws[3], steps=torch.stack(draws[4:])), **inp)
+    for i in range(n_steps):
+        assert _rel(tr["step_latents"][i], t[f"pipe.latents{i}"]) <= PIN_TOL, (i, _rel(tr["step_latents"][i], t[f"pipe.latents{i}"]))
+    assert _rel(img, t["pipe.image"]) <= PIN_TOL, _rel(img, t["pipe.image"])
+
+
+def test_oracle_pipeline_matches_reference_code_golden():
+    t, _ = _load("reference_unet_tiny.safetensors")
+    _check_pipeline_against_reference_fixture(t)
