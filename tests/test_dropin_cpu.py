@@ -69,3 +69,33 @@ def test_dropin_driver_matches_the_call_surface_of_inference_py(tmp_path):
     assert c["image"]["shape"] == [1, 3, 256, 256] and c["ip_hidden_states"]["shape"] == [2, 257, 128]
     assert c["prompt_embeds"]["shape"] == [1, 77, 128] and c["noise"]["steps"]["shape"] == [4, 1, 4, 32, 32]
     assert sorted(os.listdir(out)) == ["00000_00.jpg", "00001_00.jpg"]
+
+
+REF_DC = "/root/reference/inference_dc.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DC), reason="reference checkout not present (GPU box)")
+def test_unmodified_inference_dc_py_runs_against_this_repository(tmp_path):
+    """the DressCode script (same model call as inference.py:550; its own DresscodeTestDataset + get_agnostic mask
+    synthesis, inference_dc.py:96-352) unmodified.  It hard-codes the hub id "yisol/IDM-VTON-DC" for the UNet (:391), so the run
+    directory holds that relative path pointing at the synthetic TryonNet; cv2.dilate comes from the name shim."""
+    ck, _ = _make_assets(tmp_path, n=1)
+    dd = str(tmp_path / "dc")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_dresscode.py"), dd, "--width", "256", "--height", "256"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = tmp_path / "run"
+    (run / "yisol" / "IDM-VTON-DC").mkdir(parents=True)
+    os.symlink(os.path.join(ck, "unet"), str(run / "yisol" / "IDM-VTON-DC" / "unet"))
+    out, rec = str(tmp_path / "out"), str(tmp_path / "rec.json")
+    env["IDMVTON_DROPIN_RECORD"] = rec
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_launcher.py"), REF_DC, "--pretrained_model_name_or_path", ck,
+                        "--data_dir", dd, "--width", "256", "--height", "256", "--num_inference_steps", "4", "--output_dir", out,
+                        "--test_batch_size", "2", "--category", "upper_body"], capture_output=True, text=True, env=env, cwd=str(run), timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    c = json.load(open(rec))[0]
+    assert c["image"]["shape"] == [2, 3, 256, 256] and c["mask_image"]["shape"] == [2, 1, 256, 256]
+    assert (c["mask_image"]["min"], c["mask_image"]["max"]) == (0.0, 1.0)          # get_agnostic produced a real 0/1 inpainting mask
+    assert c["ip_hidden_states"]["shape"] == [4, 257, 128] and c["noise"]["steps"]["shape"] == [4, 2, 4, 32, 32]
+    assert sorted(os.listdir(out)) == ["000000_0.jpg", "000001_0.jpg"]
