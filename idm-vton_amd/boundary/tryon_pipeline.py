@@ -5,9 +5,9 @@ prepare_ip_adapter_image_embeds :485-507, encode_prompt :511-743, check_inputs :
 inference.py:316-414 / gradio_demo/app.py:111-234 take: same constructor components, `from_pretrained(path, unet=, vae=, ...)`,
 `.to(device)`, `.device`, `encode_prompt(...)` -> 4-tuple, `__call__(...)` keyword surface -> `(list[PIL.Image],)`.
 
-What runs where: the two CLIP text encoders and the CLIP-H image encoder are whatever modules the caller passes (the
-reference passes transformers models; they run once per call, outside the hot path -- SURVEY.md 8a row a17 / 8f-1).
-Everything from the VAE encodes to the VAE decode runs on the HIP kernels through idm_vton_amd.pipeline.TryonEngine:
+What runs where: the two CLIP text encoders and the CLIP-H image encoder are the transformers modules the caller passes; when
+they are transformers CLIP towers living on the GPU their forward is executed by idm_vton_amd.clip on the HIP kernels (SURVEY.md
+8a row a17 / 8f-1; once per call, outside the loop), any other module is called as is.  Everything from the VAE encodes to the VAE decode runs on the HIP kernels through idm_vton_amd.pipeline.TryonEngine:
 3 VAE encodes, Resampler, hoisted K/V + embedding tables, the denoising loop (GarmentNet || TryonNet on two streams,
 hipGraph replay) and the decode.  RNG draws follow the reference's order with the caller's generator.
 
@@ -23,7 +23,9 @@ import numpy as np
 import torch
 
 from .. import ffi
+from ..clip import HipCLIPText, HipCLIPVision
 from ..pipeline import TryonEngine
+from .modules import params_version
 from .scheduler import DDIMScheduler, DDPMScheduler
 from .unet import GarmentUNet2DConditionModel, TryonUNet2DConditionModel
 from .vae import AutoencoderKL
@@ -80,6 +82,7 @@ class StableDiffusionXLInpaintPipeline:
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
         self._device = torch.device("cpu")
         self._engine, self._engine_key = None, None
+        self._clip = {}                                     # name -> (params_version, HipCLIPText | HipCLIPVision)
         self._guidance_scale = 7.5
         self.use_graph, self.overlap = True, True          # engine execution mode (hipGraph replay, two-stream loop)
 
@@ -144,17 +147,41 @@ class StableDiffusionXLInpaintPipeline:
         return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None
 
     # ------------------------------------------------------------------------------------------ conditioning encoders
+    def _hip_clip(self, name):
+        """The HIP executor (idm_vton_amd.clip) of a transformers CLIP tower that lives on the GPU: prepared weights are cached and
+        rebuilt when the module's parameters change.  None for a module on the CPU or one that is not a transformers CLIP tower
+        (a caller's own encoder is called as is)."""
+        mod = getattr(self, name)
+        kind = getattr(getattr(mod, "config", None), "model_type", None)
+        p0 = next(mod.parameters())
+        if kind not in ("clip_text_model", "clip_vision_model") or not p0.is_cuda:
+            return None
+        ffi.lib()
+        key = params_version(mod)
+        hit = self._clip.get(name)
+        if hit is None or hit[0] != key:
+            dt = p0.dtype if p0.dtype in (torch.float16, torch.bfloat16) else torch.bfloat16     # fp32 module: bf16 storage, as the VAE
+            cls = HipCLIPVision if kind == "clip_vision_model" else HipCLIPText
+            hit = self._clip[name] = (key, cls(mod.state_dict(), mod.config, dt, p0.device))
+        return hit[1]
+
     def encode_image(self, image, device, num_images_per_prompt, output_hidden_states=None):
         """CLIP-H penultimate hidden states of the garment image and of an all-zero image (reference :460-482)."""
         dtype = next(self.image_encoder.parameters()).dtype
         if not isinstance(image, torch.Tensor):
             image = self.feature_extractor(image, return_tensors="pt").pixel_values
         image = image.to(device=device, dtype=dtype)
+        hip = self._hip_clip("image_encoder")
         if output_hidden_states:
-            pos = self.image_encoder(image, output_hidden_states=True).hidden_states[-2]
-            neg = self.image_encoder(torch.zeros_like(image), output_hidden_states=True).hidden_states[-2]
+            if hip is not None:                                                  # both images in one pass of the tower
+                hs = hip(torch.cat([image, torch.zeros_like(image)]), penultimate_only=True).hidden_states[-2].to(dtype)
+                pos, neg = hs[:image.shape[0]], hs[image.shape[0]:]
+            else:
+                pos = self.image_encoder(image, output_hidden_states=True).hidden_states[-2]
+                neg = self.image_encoder(torch.zeros_like(image), output_hidden_states=True).hidden_states[-2]
             return (pos.repeat_interleave(num_images_per_prompt, dim=0), neg.repeat_interleave(num_images_per_prompt, dim=0))
-        emb = self.image_encoder(image).image_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        emb = (hip(image).image_embeds.to(dtype) if hip is not None else self.image_encoder(image).image_embeds)
+        emb = emb.repeat_interleave(num_images_per_prompt, dim=0)
         return emb, torch.zeros_like(emb)
 
     def prepare_ip_adapter_image_embeds(self, ip_adapter_image, device, num_images_per_prompt):
@@ -169,9 +196,17 @@ class StableDiffusionXLInpaintPipeline:
         if len(texts) == 2 and len(tokenizers) == 1:
             texts = texts[1:]
         hidden, pooled = [], None
-        for text, tok, enc in zip(texts, tokenizers, encoders):
+        names = ["text_encoder", "text_encoder_2"][-len(encoders):]
+        for i, (text, tok, enc, name) in enumerate(zip(texts, tokenizers, encoders, names)):
             ids = tok(text, padding="max_length", max_length=max_length or tok.model_max_length, truncation=True,
                       return_tensors="pt").input_ids
+            hip = self._hip_clip(name)
+            if hip is not None:
+                last_tower = i == len(encoders) - 1           # earlier towers: only hidden_states[-2] is consumed
+                out = hip(ids.to(device), penultimate_only=not last_tower)
+                pooled = out.first.to(enc.dtype) if last_tower else None
+                hidden.append(out.hidden_states[-2].to(enc.dtype))
+                continue
             out = enc(ids.to(device), output_hidden_states=True)
             pooled = out[0]                               # the LAST encoder's first output: pooled text_embeds of encoder 2
             hidden.append(out.hidden_states[-2])

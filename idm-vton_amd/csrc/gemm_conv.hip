@@ -329,6 +329,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
                 if (p.mode == IDMVTON_EPI_GELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                } else if (p.mode == IDMVTON_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
                 }
                 if (res) {
                     const v4 rr = *(const v4*)(res + (size_t)m * p.ldr + n);
@@ -440,7 +443,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     const uint64_t wbytes = (uint64_t)a->N * a->Ktot * 2;
     CHECK_ARG(wbytes + (uint64_t)128 * a->Ktot * 2 < 0xFFFFFFFFull, IDMVTON_E_SHAPE, "gemm_conv: weight too large");
     const bool geglu = a->mode == IDMVTON_EPI_GEGLU;
-    CHECK_ARG(a->mode == IDMVTON_EPI_NONE || a->mode == IDMVTON_EPI_GELU || geglu, IDMVTON_E_ARG, "gemm_conv: mode %d", a->mode);
+    CHECK_ARG(a->mode == IDMVTON_EPI_NONE || a->mode == IDMVTON_EPI_GELU || a->mode == IDMVTON_EPI_QUICKGELU || geglu, IDMVTON_E_ARG, "gemm_conv: mode %d", a->mode);
     CHECK_ARG(a->colscale_n >= 0 && a->colscale_n % 4 == 0 && !(geglu && a->colscale_n), IDMVTON_E_ARG, "gemm_conv: colscale_n=%d", a->colscale_n);
     if (geglu) CHECK_ARG(a->N % 64 == 0 && !a->res && !a->rowbias && !a->vt, IDMVTON_E_ARG, "gemm_conv: GEGLU needs N%%64==0, no res/rowbias/vt");
     CHECK_ARG(a->out || (a->vt && a->vt_n0 == 0), IDMVTON_E_ARG, "gemm_conv: null out");

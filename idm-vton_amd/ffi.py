@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_hip.so")   # override: A/B of library builds
 
 F16, BF16, F32 = 0, 1, 2
-EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
+EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS = 0, 1
 MAX_SEG = 12
 
@@ -64,6 +64,11 @@ class VaeSampleArgs(C.Structure):
                 ("scale", f32)]
 
 
+class AttnSmallArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("d", i32), ("q", vp), ("ldq", i32),
+                ("k", vp), ("ldk", i32), ("v", vp), ("ldv", i32), ("out", vp), ("ldo", i32), ("scale", f32), ("causal", i32)]
+
+
 class SoftmaxArgs(C.Structure):
     _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32)]
 
@@ -71,13 +76,14 @@ class SoftmaxArgs(C.Structure):
 STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_attn_args": AttnArgs,
            "idmvton_layernorm_args": LayerNormArgs, "idmvton_groupnorm_args": GroupNormArgs,
            "idmvton_pack_input_args": PackInputArgs, "idmvton_cfg_step_args": CfgStepArgs,
-           "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs, "idmvton_softmax_args": SoftmaxArgs}
+           "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs, "idmvton_softmax_args": SoftmaxArgs,
+           "idmvton_attn_small_args": AttnSmallArgs}
 
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
            "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles",
-           "idmvton_prefetch"]
+           "idmvton_prefetch", "idmvton_attn_small"]
 
 _lib = None
 
@@ -105,7 +111,8 @@ def lib():
         if n != C.sizeof(st):
             raise HipLibraryMissing(f"ABI drift: sizeof({name}) is {n} in the library, {C.sizeof(st)} in ffi.py")
     for s in ("idmvton_gemm_conv", "idmvton_attn_fwd", "idmvton_layernorm", "idmvton_groupnorm",
-              "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout", "idmvton_vae_sample", "idmvton_softmax_rows"):
+              "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout", "idmvton_vae_sample", "idmvton_softmax_rows",
+              "idmvton_attn_small"):
         getattr(L, s).argtypes = [vp, vp]
         getattr(L, s).restype = C.c_int
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]

@@ -87,7 +87,7 @@ class SegSpec:
 
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
-              rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, vt=None,
+              rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, quick_gelu=False, vt=None,
               vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
@@ -116,7 +116,7 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.rowbias, a.rowbias_ld, a.rows_per_group = _ptr(rowbias), rowbias_ld, rows_per_group
     a.res = _ptr(res)
     a.ldr = (ldr if ldr is not None else (res.stride(-2) if res is not None else 0))
-    a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else ffi.EPI_NONE)
+    a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else (ffi.EPI_QUICKGELU if quick_gelu else ffi.EPI_NONE))
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.colscale_n, a.colscale = colscale_n, colscale
@@ -190,6 +190,23 @@ def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, 
     for s in segs:
         fl += 4.0 * (a.B - s.get("b0", 0)) * heads * a.Nq * s["nk"] * 64
     _call("idmvton_attn_fwd", a, flops=fl, bytes_=2.0 * a.B * a.Nq * heads * 64 * q.element_size())
+    return out
+
+
+def attention_small(q, k, v, out, heads, d, *, scale, causal=False, B=None, Lq=None, Lk=None, ldq=None, ldk=None, ldv=None, ldo=None):
+    """softmax(scale * q k^T [causal]) v, any even head_dim <= 128 (the CLIP towers).  q/out: [B][Lq][>= heads*d], k/v: [B][Lk][...]."""
+    a = ffi.AttnSmallArgs()
+    a.dtype = _dt(q)
+    a.B = q.shape[0] if B is None else B
+    a.heads, a.d = heads, d
+    a.Lq = q.shape[1] if Lq is None else Lq
+    a.Lk = k.shape[1] if Lk is None else Lk
+    a.q, a.ldq = _ptr(q), (q.stride(-2) if ldq is None else ldq)
+    a.k, a.ldk = _ptr(k), (k.stride(-2) if ldk is None else ldk)
+    a.v, a.ldv = _ptr(v), (v.stride(-2) if ldv is None else ldv)
+    a.out, a.ldo = _ptr(out), (out.stride(-2) if ldo is None else ldo)
+    a.scale, a.causal = scale, int(bool(causal))
+    _call("idmvton_attn_small", a, flops=4.0 * a.B * heads * a.Lq * a.Lk * d)
     return out
 
 

@@ -61,7 +61,8 @@ typedef struct {
     int32_t dy, dx;  /* tap offset, padding already folded in       */
 } idmvton_seg;
 
-enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1, IDMVTON_EPI_GELU = 2 /* gelu_erf(acc+bias+rowbias) then +res */ };
+enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1, IDMVTON_EPI_GELU = 2 /* gelu_erf(acc+bias+rowbias) then +res */,
+       IDMVTON_EPI_QUICKGELU = 3 /* x*sigmoid(1.702x): CLIP-L text MLP (transformers hidden_act "quick_gelu") */ };
 typedef struct {
     int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type) */
     const void* w; int32_t N; int32_t Ktot;
@@ -127,6 +128,22 @@ typedef struct {
                                     applies it in fp32 in the projection epilogue, same single rounding as an unscaled q) */
 } idmvton_attn_args;
 int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_attn_small : softmax(scale * q k^T [+ causal mask]) v for the one-off conditioning encoders -- the CLIP text towers
+ * (transformers CLIPTextModel / CLIPTextModelWithProjection as called at src/tryon_pipeline.py:511-743: 77 tokens, causal) and
+ * the CLIP-H vision tower (:460-482: 257 tokens, head_dim 80).  Any even head_dim <= 128, Lk <= 1024, fp32 arithmetic; one wave
+ * per query row.  q/k/v/out: [B][L][ld*], head h at columns [h*d, h*d + d).  causal: row i sees keys j <= i + (Lk - Lq).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype; int32_t B, heads, Lq, Lk, d;
+    const void* q; int32_t ldq;
+    const void* k; int32_t ldk;
+    const void* v; int32_t ldv;
+    void* out; int32_t ldo;
+    float scale; int32_t causal;
+} idmvton_attn_small_args;
+int idmvton_attn_small(const idmvton_attn_small_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * idmvton_layernorm : y = LN(x)*gamma+beta over the last dim, fp32 statistics (eps inside sqrt), optional second copy.

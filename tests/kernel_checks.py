@@ -296,6 +296,31 @@ def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, 
     return relerr(out, ref)
 
 
+def check_attn_small(B, heads, L, d, dtype, dev, causal, Lq=None, seed=0, scale=1.0):
+    """idmvton_attn_small (CLIP towers): fused-QKV layout, any even head_dim <= 128, optional causal mask."""
+    from idm_vton_amd import ops
+    H, Lq = heads * d, (L if Lq is None else Lq)
+    qkv = _r(B, L, 3 * H, dtype=dtype, dev=dev, seed=seed, scale=scale)
+    q, k, v = qkv[:, L - Lq:, :H].contiguous(), qkv[:, :, H:2 * H], qkv[:, :, 2 * H:]
+    sp = lambda t: t.float().reshape(B, t.shape[1], heads, d).transpose(1, 2)
+    mask = None
+    if causal:
+        mask = torch.ones(Lq, L, dtype=torch.bool, device=dev).tril(diagonal=L - Lq)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), attn_mask=mask).transpose(1, 2).reshape(B, Lq, H)
+    out = torch.empty(B, Lq, H, dtype=dtype, device=dev)
+    ops.attention_small(q, k, v, out, heads, d, scale=d ** -0.5, causal=causal, B=B, Lq=Lq, Lk=L, ldq=H, ldk=3 * H, ldv=3 * H, ldo=H)
+    return relerr(out, ref)
+
+
+def check_quickgelu(dtype, dev):
+    """quick_gelu epilogue (CLIP-L MLP): (x W^T + b) * sigmoid(1.702 (x W^T + b)), then + residual."""
+    from idm_vton_amd import ops
+    M, N, K = 154, 3072, 768
+    x, w, b = _r(M, K, dtype=dtype, dev=dev), _r(N, K, dtype=dtype, dev=dev, scale=2 * K ** -0.5, seed=1), _r(N, dtype=dtype, dev=dev, seed=2)
+    pre = x.float() @ w.float().t() + b.float()
+    return relerr(ops.linear(x, w, bias=b, quick_gelu=True), pre * torch.sigmoid(1.702 * pre))
+
+
 # ------------------------------------------------------------------------------------------------ norms / elementwise
 def check_layernorm(rows, Cc, dtype, dev, seed=0):
     from idm_vton_amd import ops
@@ -457,6 +482,12 @@ def all_checks(dev="cuda"):
             add(f"attn_self_prescaled_ragged_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn, prescaled=True))
             add(f"attn_self_neg_logits_{tag}", lambda dt=dt, tn=tn: check_attn_neg(dt, dev, tune=tn))
         add("linear_colscale", lambda dt=dt: check_colscale(dt, dev))
+        add("linear_quickgelu", lambda dt=dt: check_quickgelu(dt, dev))
+        add("attn_small_text_causal_77_d64", lambda dt=dt: check_attn_small(2, 12, 77, 64, dt, dev, True))
+        add("attn_small_vision_257_d80", lambda dt=dt: check_attn_small(2, 16, 257, 80, dt, dev, False))
+        add("attn_small_causal_offset_d32", lambda dt=dt: check_attn_small(3, 2, 100, 32, dt, dev, True, Lq=37))
+        add("attn_small_big_logits_d128", lambda dt=dt: check_attn_small(1, 2, 300, 128, dt, dev, False, scale=4.0))
+        add("attn_small_L1", lambda dt=dt: check_attn_small(2, 2, 1, 64, dt, dev, True))
         add("attn_self_1seg_N768", lambda dt=dt: check_attn_self(2, 4, 768, dt, dev))
         add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
         add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))

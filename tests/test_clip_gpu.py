@@ -1,0 +1,126 @@
+"""CLIP towers on the HIP kernels (idm_vton_amd.clip) against the transformers modules themselves --
+the dependency the reference calls at src/tryon_pipeline.py:460-482 (vision) and :511-743 (text) -- run in fp32 on the host.
+
+Tolerances: relative Frobenius error of 16-bit storage through 2..4 pre-LN layers, measured ~2e-3 (fp16) / ~1.2e-2 (bf16)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BAR = {torch.float16: 6e-3, torch.bfloat16: 3e-2}
+
+
+def relerr(x, ref):
+    return ((x.float().cpu() - ref.float()).norm() / ref.float().norm().clamp_min(1e-12)).item()
+
+
+def _text(hidden, heads, layers, act, proj, vocab=1000, eos=999, seed=0):
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    torch.manual_seed(seed)
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=4 * hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                         max_position_embeddings=77, projection_dim=proj or 64, hidden_act=act, bos_token_id=vocab - 2, eos_token_id=eos, pad_token_id=eos)
+    m = (CLIPTextModelWithProjection if proj else CLIPTextModel)(cfg).eval()
+    with torch.no_grad():                                  # default init is tiny (std 0.02): widen so every op matters numerically
+        for n, p in m.named_parameters():
+            if p.dim() == 2 and "embedding" not in n:
+                p.mul_(3.0)
+            if n.endswith("bias"):
+                p.normal_(0, 0.1)
+    return m
+
+
+def _ids(B, L, vocab, eos, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, vocab - 2, (B, L), generator=g)
+    ids[:, 0] = vocab - 2
+    for b in range(B):                                      # EOS at a different place per row, padding (== EOS id) after it
+        ids[b, 5 + 7 * b:] = eos
+    return ids
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["L_quickgelu", "bigG_proj", "legacy_eos2"])
+def test_text_tower_matches_transformers(dtype, case):
+    from idm_vton_amd.clip import HipCLIPText
+    hidden, heads, layers, act, proj, eos = dict(L_quickgelu=(768, 12, 3, "quick_gelu", 0, 999), bigG_proj=(1280, 20, 3, "gelu", 1280, 999),
+                                                 legacy_eos2=(128, 2, 2, "quick_gelu", 64, 2))[case]
+    m = _text(hidden, heads, layers, act, proj, eos=eos)
+    ids = _ids(3, 77, 1000, 999, 1)                         # legacy (eos_token_id == 2) configs pool at argmax(ids): the first 999
+    with torch.no_grad():
+        ref = m(ids, output_hidden_states=True)
+    hip = HipCLIPText(m.state_dict(), m.config, dtype, "cuda")
+    out = hip(ids)
+    assert len(out.hidden_states) == len(ref.hidden_states) == layers + 1
+    for a, b in zip(out.hidden_states, ref.hidden_states):
+        assert relerr(a, b) < BAR[dtype]
+    assert relerr(out.last_hidden_state, ref.last_hidden_state) < BAR[dtype]
+    assert relerr(out.first, ref[0]) < BAR[dtype]           # what encode_prompt reads as `prompt_embeds[0]` (:601)
+    if proj:
+        assert relerr(out.text_embeds, ref.text_embeds) < BAR[dtype]
+    pen = hip(ids, penultimate_only=True)
+    assert torch.equal(pen.hidden_states[-2], out.hidden_states[-2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["H_d80", "tiny_d64"])
+def test_vision_tower_matches_transformers(dtype, case):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from idm_vton_amd.clip import HipCLIPVision
+    hidden, heads, layers = dict(H_d80=(1280, 16, 3), tiny_d64=(128, 2, 2))[case]
+    torch.manual_seed(2)
+    cfg = CLIPVisionConfig(hidden_size=hidden, intermediate_size=4 * hidden, num_hidden_layers=layers, num_attention_heads=heads, image_size=224,
+                           patch_size=14, projection_dim=256, hidden_act="gelu")
+    m = CLIPVisionModelWithProjection(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 2 and "embedding" not in n:
+                p.mul_(3.0)
+            if n.endswith("bias"):
+                p.normal_(0, 0.1)
+    px = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    px[1] = 0                                               # the all-zero image of encode_image (:474)
+    with torch.no_grad():
+        ref = m(px, output_hidden_states=True)
+    assert ref.hidden_states[-2].shape == (2, 257, hidden)
+    hip = HipCLIPVision(m.state_dict(), m.config, dtype, "cuda")
+    out = hip(px)
+    for a, b in zip(out.hidden_states, ref.hidden_states):
+        assert relerr(a, b) < BAR[dtype]
+    assert relerr(out.image_embeds, ref.image_embeds) < BAR[dtype]
+    pen = hip(px, penultimate_only=True)
+    assert torch.equal(pen.hidden_states[-2], out.hidden_states[-2])
+
+
+def test_pipeline_encoders_run_on_hip(tmp_path):
+    """encode_prompt / encode_image of the drop-in pipeline route transformers CLIP towers on the GPU through idm_vton_amd.clip and
+    agree with calling the modules directly."""
+    from idm_vton_amd import ops
+    from idm_vton_amd.boundary.tryon_pipeline import StableDiffusionXLInpaintPipeline as P
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    t1, t2 = _text(64, 1, 2, "quick_gelu", 0, seed=4).half().cuda(), _text(128, 2, 2, "gelu", 64, seed=5).half().cuda()
+    vis = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                                         image_size=224, patch_size=14, projection_dim=64)).half().cuda().eval()
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, text, **kw):
+            return type("E", (), {"input_ids": _ids(len(text), 77, 1000, 999, len(text[0]))})()
+
+    pipe = P.__new__(P)
+    pipe.text_encoder, pipe.text_encoder_2, pipe.tokenizer, pipe.tokenizer_2, pipe.image_encoder = t1, t2, Tok(), Tok(), vis
+    pipe._clip, pipe._device = {}, torch.device("cuda")
+    ops.RECORD = rec = []
+    try:
+        hid, pooled = pipe._encode_text([["a"], ["a"]], "cuda")
+        pos, neg = pipe.encode_image(torch.randn(1, 3, 224, 224), "cuda", 1, True)
+    finally:
+        ops.RECORD = None
+    # tower 1 stops after its penultimate layer (4 GEMMs), tower 2 runs 2 layers + text_projection (9), vision patch GEMM + 1 layer (5)
+    assert sum(r[0] == "gemm" for r in rec) == 18, "the CLIP towers did not run on the HIP GEMM"
+    ids = _ids(1, 77, 1000, 999, 1).cuda()
+    with torch.no_grad():
+        r1, r2 = t1(ids, output_hidden_states=True), t2(ids, output_hidden_states=True)
+    ref = torch.cat([r1.hidden_states[-2], r2.hidden_states[-2]], -1)
+    assert hid.shape == (1, 77, 192) and hid.dtype == torch.float16 and relerr(hid, ref.cpu()) < 6e-3
+    assert relerr(pooled, r2[0].cpu()) < 6e-3
+    assert pos.shape == neg.shape == (1, 257, 128)
