@@ -21,6 +21,7 @@
 //             instead of 64 for 128x128) and with small tiles where 1-2 blocks per CU cannot hide the HBM/L2 latency.
 // LIN = plain Linear (one K segment, no spatial gather): the activation operand's DMA offsets are precomputed like the
 // weight's, so issuing a tile costs one add per DMA instead of the ~12 VALU of the conv gather.
+#include <cstdlib>
 #include "common.cuh"
 
 struct GemmParams {
@@ -34,9 +35,229 @@ struct GemmParams {
     void* vt; int vt_n0; int vt_tokens; int vt_perm;
     int colscale_n; float colscale;
     int tiles_m, tiles_n;
+    int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Two accumulator column groups (g = 2gp, 2gp+1: columns 8g + 4u + j) of one 32x32 tile -> 8 CONSECUTIVE columns 16gp + 8u + (0..7)
+// of the lane's row: lanes 32..63 of group 2gp trade places with lanes 0..31 of group 2gp+1 (v_permlane32_swap).  The epilogue is
+// store-issue bound (one row per lane: every lane's store is its own memory segment), so 16-byte accesses halve its instruction
+// count at the same bytes.  Both lanes of a pair (l, l+32) share their row, so they are active together.
+__device__ __forceinline__ void swap_cols8(const f32x16& c, const int gp, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * gp + j]), __float_as_uint(c[8 * gp + 4 + j]), false, false);
+        v[j] = __uint_as_float(r[0]);
+        v[4 + j] = __uint_as_float(r[1]);
+    }
+}
+
+// Epilogue shared by every main loop: acc[ni][mi] is the wave's (SN x SM) sub-tile as NI x MI 32x32 accumulators (TR: D[m][n]).
+template <typename T, int NI, int MI, int SN, int SM, bool TR>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[NI][MI], const int m0, const int n0, const int wn, const int wm,
+                                              const int lane) {
+    typedef typename VT<T>::v4 v4;
+    typedef typename VT<T>::v8 v8;
+    const int u = lane >> 5, l31 = lane & 31;
+    const T* bias = (const T*)p.bias;
+    if constexpr (TR) {
+        if (p.vt_perm) {
+            // key order puts the tokens of accumulator groups g = 2gp, 2gp+1 (rows 8g + 4u + j) next to each other: 16 gp + 8u + 4(g&1) + j
+            T* vt = (T*)p.vt;
+            const int Cv = p.N - p.vt_n0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + wn * SN + ni * 32 + l31;
+                if (n >= p.N) continue;
+                const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int m = m0 + wm * SM + mi * 32 + 16 * gp;                  // vt_tokens % 16 == 0: one batch per 16 rows
+                        if (m >= p.M) continue;
+                        const int b = m / p.vt_tokens;
+                        const int tok = m - b * p.vt_tokens + 8 * u;
+                        v8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (T)(acc[ni][mi][8 * gp + j] + bv);
+                        *(v8*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
+                    }
+            }
+            return;
+        }
+        // acc[ni][mi] = D[m][n]: column n = l31, rows m = 8g + 4u + j.  vt[(b*Cv + n - vt_n0)*tokens + tok..tok+3]
+        T* vt = (T*)p.vt;
+        const int Cv = p.N - p.vt_n0;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * SN + ni * 32 + l31;
+            if (n >= p.N) continue;
+            const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = m0 + wm * SM + mi * 32 + 8 * g + 4 * u;
+                    if (m >= p.M) continue;
+                    const int b = m / p.vt_tokens;
+                    int tok = m - b * p.vt_tokens;
+                    // attention key order: bits 2 and 3 of the token index swapped inside every group of 16, so that the 8 keys a
+                    // half-wave contracts in one PV MFMA (QK^T accumulator rows 8g+4u..+3, g = 0,1) are 16 contiguous bytes of V^T
+                    if (p.vt_perm) tok = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
+                    v4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
+                    *(v4*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
+                }
+        }
+        return;
+    }
+    T* out = (T*)p.out;
+    const T* res = (const T*)p.res;
+    const T* rowbias = (const T*)p.rowbias;
+    if (p.wide) {                                        // block-uniform: 16-byte loads / stores, 8 columns per lane and access
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * SM + mi * 32 + l31;
+            if (m >= p.M) continue;
+            const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
+            if (p.mode == IDMVTON_EPI_GEGLU) {
+                if constexpr (NI % 2 == 0) {
+#pragma unroll
+                    for (int pr = 0; pr < NI / 2; ++pr)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            float h[8], gt[8];
+                            swap_cols8(acc[2 * pr][mi], gp, h);
+                            swap_cols8(acc[2 * pr + 1][mi], gp, gt);
+                            const int nh = n0 + wn * SN + pr * 64 + 16 * gp + 8 * u;   // h rows; gate rows are nh + 32
+                            if (nh + 32 >= p.N) continue;
+                            const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 16 * gp + 8 * u;
+                            if (bias) {
+                                const v8 bh = *(const v8*)(bias + nh), bg = *(const v8*)(bias + nh + 32);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) { h[j] += (float)bh[j]; gt[j] += (float)bg[j]; }
+                            }
+                            v8 o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = (T)(h[j] * gelu_erf(gt[j]));
+                            *(v8*)(out + (size_t)m * p.ldo + jo) = o;
+                        }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    float v[8];
+                    swap_cols8(acc[ni][mi], gp, v);
+                    const int n = n0 + wn * SN + ni * 32 + 16 * gp + 8 * u;
+                    if (n >= p.N) continue;
+                    if (bias) {
+                        const v8 bb = *(const v8*)(bias + n);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)bb[j];
+                    }
+                    if (rb) {
+                        const v8 bb = *(const v8*)(rb + n);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)bb[j];
+                    }
+                    if (n < p.colscale_n) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= p.colscale;
+                    }
+                    if (p.mode == IDMVTON_EPI_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+                    } else if (p.mode == IDMVTON_EPI_QUICKGELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
+                    }
+                    if (res) {
+                        const v8 rr = *(const v8*)(res + (size_t)m * p.ldr + n);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+                    }
+                    v8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
+                    *(v8*)(out + (size_t)m * p.ldo + n) = o;
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * SM + mi * 32 + l31;
+        if (m >= p.M) continue;
+        const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
+        if (p.mode == IDMVTON_EPI_GEGLU) {
+            if constexpr (NI % 2 == 0) {
+#pragma unroll
+                for (int pr = 0; pr < NI / 2; ++pr)          // 64-row weight blocks [32 h | 32 gate] of this wave
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nh = n0 + wn * SN + pr * 64 + 8 * g + 4 * u;     // h rows; gate rows are nh + 32
+                        if (nh + 32 >= p.N) continue;
+                        const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 8 * g + 4 * u;
+                        v4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float h = acc[2 * pr][mi][4 * g + j], gt = acc[2 * pr + 1][mi][4 * g + j];
+                            if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
+                            o[j] = (T)(h * gelu_erf(gt));
+                        }
+                        *(v4*)(out + (size_t)m * p.ldo + jo) = o;
+                    }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * SN + ni * 32 + 8 * g + 4 * u;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                if (bias) {
+                    const v4 bb = *(const v4*)(bias + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)bb[j];
+                }
+                if (rb) {
+                    const v4 bb = *(const v4*)(rb + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)bb[j];
+                }
+                if (n < p.colscale_n) {                    // e.g. the q columns of a fused QKV projection: softmax scale in fp32
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= p.colscale;
+                }
+                if (p.mode == IDMVTON_EPI_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                } else if (p.mode == IDMVTON_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
+                }
+                if (res) {
+                    const v4 rr = *(const v4*)(res + (size_t)m * p.ldr + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
+                }
+                v4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                *(v4*)(out + (size_t)m * p.ldo + n) = o;
+            }
+    }
+}
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
@@ -244,106 +465,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     }
 
-    // ---- epilogue ----
-    const T* bias = (const T*)p.bias;
-    if constexpr (TR) {
-        // acc[ni][mi] = D[m][n]: column n = l31, rows m = 8g + 4u + j.  vt[(b*Cv + n - vt_n0)*tokens + tok..tok+3]
-        T* vt = (T*)p.vt;
-        const int Cv = p.N - p.vt_n0;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * SN + ni * 32 + l31;
-            if (n >= p.N) continue;
-            const float bv = bias ? (float)bias[n] : 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int m = m0 + wm * SM + mi * 32 + 8 * g + 4 * u;
-                    if (m >= p.M) continue;
-                    const int b = m / p.vt_tokens;
-                    int tok = m - b * p.vt_tokens;
-                    // attention key order: bits 2 and 3 of the token index swapped inside every group of 16, so that the 8 keys a
-                    // half-wave contracts in one PV MFMA (QK^T accumulator rows 8g+4u..+3, g = 0,1) are 16 contiguous bytes of V^T
-                    if (p.vt_perm) tok = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
-                    v4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
-                    *(v4*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
-                }
-        }
-        return;
-    }
-    T* out = (T*)p.out;
-    const T* res = (const T*)p.res;
-    const T* rowbias = (const T*)p.rowbias;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * SM + mi * 32 + l31;
-        if (m >= p.M) continue;
-        const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
-        if (p.mode == IDMVTON_EPI_GEGLU) {
-            if constexpr (NI % 2 == 0) {
-#pragma unroll
-                for (int pr = 0; pr < NI / 2; ++pr)          // 64-row weight blocks [32 h | 32 gate] of this wave
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nh = n0 + wn * SN + pr * 64 + 8 * g + 4 * u;     // h rows; gate rows are nh + 32
-                        if (nh + 32 >= p.N) continue;
-                        const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 8 * g + 4 * u;
-                        v4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float h = acc[2 * pr][mi][4 * g + j], gt = acc[2 * pr + 1][mi][4 * g + j];
-                            if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
-                            o[j] = (T)(h * gelu_erf(gt));
-                        }
-                        *(v4*)(out + (size_t)m * p.ldo + jo) = o;
-                    }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * SN + ni * 32 + 8 * g + 4 * u;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-                if (bias) {
-                    const v4 bb = *(const v4*)(bias + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)bb[j];
-                }
-                if (rb) {
-                    const v4 bb = *(const v4*)(rb + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)bb[j];
-                }
-                if (n < p.colscale_n) {                    // e.g. the q columns of a fused QKV projection: softmax scale in fp32
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= p.colscale;
-                }
-                if (p.mode == IDMVTON_EPI_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                } else if (p.mode == IDMVTON_EPI_QUICKGELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
-                }
-                if (res) {
-                    const v4 rr = *(const v4*)(res + (size_t)m * p.ldr + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
-                }
-                v4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
-                *(v4*)(out + (size_t)m * p.ldo + n) = o;
-            }
-    }
+    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane);
 }
 
 // Tile configurations.  id = the `variant` field of tile_hint (bits 28..31); BN/BM in bits 16..27 / 0..15.
@@ -359,6 +481,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 //    denoising step 46.6 vs 46.3 ms, profiles/r02_bench_prefetch_ab.txt): removed.  A fourth: the next tile's DMA front-loaded
 //    into the first one or two k-steps of the 8-wave tiles instead of spread over all four: -3..+3 %
 //    (profiles/r02_probe_gemm_v4.log): removed.)
+//   (also measured and removed in round 2, profiles/r02_gemm_ksweep_v3_w4_pp.json + r02_pmc_gemm_vs_hipblaslt.txt: a 256x256
+//    ping-pong kernel -- five 32-deep LDS stages, counted vmcnt, two wave groups one barrier apart, s_setprio around 16-MFMA blocks --
+//    raised MFMA-busy from 63 % to 75 % of the kernel's CYCLES on 8192^3, and the clock fell from 1.83 to 1.53 GHz: the same wall
+//    time.  Large GEMMs on this part are power-limited; the library kernel it was compared with, hipBLASLt MT256x256x64 with 4 waves
+//    of 128x128, is 87 % MFMA-busy at 1.5 GHz.  A 4-wave 128x128-per-wave instantiation of this file's loop had the same slope.)
 //   v2                : the v1 tiles (except 128x128, which already has it) with the fragments of k-step s+1 read from LDS
 //                       ahead of the MFMAs of step s (PMC: 45 % of wave cycles of the 8-wave tiles sit in s_waitcnt, mostly
 //                       lgkmcnt in front of each k-step; both waves of a SIMD are barrier-aligned so neither covers the other)
@@ -452,6 +579,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     if (a->bias) CHECK_ARG(((uintptr_t)a->bias & 7) == 0, IDMVTON_E_ALIGN, "gemm_conv: bias alignment");
     if (a->rowbias) CHECK_ARG(a->rowbias_ld % 4 == 0 && a->rows_per_group > 0 && ((uintptr_t)a->rowbias & 7) == 0,
                               IDMVTON_E_ALIGN, "gemm_conv: rowbias");
+    if (a->vt && a->vt_perm) CHECK_ARG(((uintptr_t)a->vt & 15) == 0, IDMVTON_E_ALIGN, "gemm_conv: vt pointer not 16-byte aligned");
     if (a->vt && a->vt_perm) CHECK_ARG(a->vt_tokens % 16 == 0, IDMVTON_E_ARG, "gemm_conv: vt_perm needs vt_tokens %% 16 == 0 (got %d)", a->vt_tokens);
     if (a->vt) CHECK_ARG(a->vt_tokens > 0 && a->vt_tokens % 4 == 0 && a->M % a->vt_tokens == 0 && a->vt_n0 % 64 == 0 &&
                          a->vt_n0 >= 0 && a->vt_n0 < a->N && ((uintptr_t)a->vt & 7) == 0,
@@ -467,10 +595,19 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4; p.vt_perm = a->vt_perm ? 1 : 0;
     p.colscale_n = a->colscale_n; p.colscale = a->colscale;
     p.tiles_m = p.tiles_n = 0;
+    {
+        auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+        const int n_out = geglu ? a->N / 2 : a->N;
+        p.wide = n_out % 8 == 0 && a->N % 8 == 0 && a->colscale_n % 8 == 0 && (!a->out || (a->ldo % 8 == 0 && a16(a->out))) &&
+                 (!a->res || (a->ldr % 8 == 0 && a16(a->res))) && (!a->bias || a16(a->bias)) &&
+                 (!a->rowbias || (a->rowbias_ld % 8 == 0 && a16(a->rowbias))) && (!a->vt || a->vt_n0 % 8 == 0);
+    }
 
     // Tile choice: tile_hint (variant<<28 | BN<<16 | BM) from the caller's tuning table; GEGLU needs 64-row wave tiles (BN >= 128).
     int variant = 1, bn = 64, bm = 64;
-    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0xffff; }
+    static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
+    if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
+    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0x7fff; }
     else {
         // No hint: the largest ring tile that still gives every CU a tile (measured rule, profiles/r01_tune_report_*.json:
         // operand delivery per CU is the bound, so arithmetic intensity per tile wins until the grid no longer fills 256 CUs).

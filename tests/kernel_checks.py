@@ -417,6 +417,8 @@ def all_checks(dev="cuda"):
             add(f"ring_linear_ragged_1000x328x192_{tag}", lambda dt=dt, hint=hint: check_linear(1000, 328, 192, dt, dev, rowbias=True, tile_hint=hint))
             add(f"ring_linear_K64_{tag}", lambda dt=dt, hint=hint: check_linear(300, 192, 64, dt, dev, tile_hint=hint))
             add(f"ring_linear_K128_{tag}", lambda dt=dt, hint=hint: check_linear(2500, 136, 128, dt, dev, tile_hint=hint))
+            add(f"ring_linear_K192_{tag}", lambda dt=dt, hint=hint: check_linear(520, 264, 192, dt, dev, tile_hint=hint))
+            add(f"ring_linear_K320_{tag}", lambda dt=dt, hint=hint: check_linear(515, 520, 320, dt, dev, rowbias=True, tile_hint=hint))
             add(f"ring_linear_3072x1280x1280_{tag}", lambda dt=dt, hint=hint: check_linear(3072, 1280, 1280, dt, dev, tile_hint=hint))
             add(f"ring_vt_B2_N768_C640_{tag}", lambda dt=dt, hint=hint: check_vt(2, 768, 640, dt, dev, tile_hint=hint))
             add(f"ring_conv3x3_320_32x24_{tag}", lambda dt=dt, hint=hint: check_conv(2, 320, 320, 32, 24, dt, dev, temb=True, tile_hint=hint))
@@ -428,6 +430,10 @@ def all_checks(dev="cuda"):
                 add(f"ring_geglu_1536x640_{tag}", lambda dt=dt, hint=hint: check_geglu(1536, 640, dt, dev, tile_hint=hint))
                 add(f"ring_geglu_ragged_200x64_{tag}", lambda dt=dt, hint=hint: check_geglu(200, 64, dt, dev, tile_hint=hint))
         add("linear_ragged_200x328x192", lambda dt=dt: check_linear(200, 328, 192, dt, dev, rowbias=True))
+        # 8-byte epilogue: forced (bit 15 of the hint) and by shape (N % 8 != 0)
+        add("linear_768x640x640_narrow", lambda dt=dt: check_linear(768, 640, 640, dt, dev, rowbias=True, tile_hint=_hint(1, 128, 64) | 0x8000))
+        add("linear_N324_narrow", lambda dt=dt: check_linear(500, 324, 128, dt, dev, rowbias=False))
+        add("geglu_1536x640_narrow", lambda dt=dt: check_geglu(1536, 640, dt, dev, tile_hint=_hint(1, 128, 256) | 0x8000))
         add("linear_M4_temb", lambda dt=dt: check_linear(4, 1280, 1280, dt, dev, res=False))
         add("linear_3072x1280x1280", lambda dt=dt: check_linear(3072, 1280, 1280, dt, dev))
         add("linear_crossKV_308x640x2048", lambda dt=dt: check_linear(308, 640, 2048, dt, dev, bias=False, res=False))
