@@ -281,16 +281,18 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
     const float lt = xhalf_sum(l_run);
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     const float sc = MODE == IDMVTON_ATTN_CROSS ? p.ip_scale * inv : inv;
-    if (q_row < p.Nq) {
-        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 4 * u;
+    if (q_row < p.Nq) {                                  // both lanes of a pair (l, l+32) hold the same query row
+        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 8 * u;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                v4 o;
+            for (int gp = 0; gp < 2; ++gp) {
+                v4 o[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (T)(ofin[db][4 * g + j] + oacc[db][4 * g + j] * sc);
-                *(v4*)(op + db * 32 + 8 * g) = o;
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[k][j] = (T)(ofin[db][8 * gp + 4 * k + j] + oacc[db][8 * gp + 4 * k + j] * sc);
+                store_cols8(op + db * 32 + 16 * gp, o[0], o[1]);
             }
     }
 }
@@ -579,15 +581,17 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
     const float lt = xhalf_sum(l_run);
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     if (q_row < p.Nq) {
-        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 4 * u;
+        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 8 * u;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                v4 o;
+            for (int gp = 0; gp < 2; ++gp) {
+                v4 o[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (T)(oacc[db][4 * g + j] * inv);
-                *(v4*)(op + db * 32 + 8 * g) = o;
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[k][j] = (T)(oacc[db][8 * gp + 4 * k + j] * inv);
+                store_cols8(op + db * 32 + 16 * gp, o[0], o[1]);
             }
     }
 }
@@ -658,7 +662,7 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
     CHECK_ARG(a->nseg >= 1 && a->nseg <= 2, IDMVTON_E_SHAPE, "attn_fwd: nseg=%d", a->nseg);
     if (a->mode == IDMVTON_ATTN_CROSS) CHECK_ARG(a->nseg == 2 && a->seg_b0[0] == 0 && a->seg_b0[1] == 0, IDMVTON_E_ARG,
                                                  "attn_fwd: CROSS needs two segments present for every batch");
-    CHECK_ARG(a->q && a->out && a->ldq % 8 == 0 && a->ldo % 4 == 0 && ((uintptr_t)a->q & 15) == 0 && ((uintptr_t)a->out & 7) == 0,
+    CHECK_ARG(a->q && a->out && a->ldq % 8 == 0 && a->ldo % 8 == 0 && ((uintptr_t)a->q & 15) == 0 && ((uintptr_t)a->out & 15) == 0,
               IDMVTON_E_ALIGN, "attn_fwd: q/out alignment (ldq=%d ldo=%d)", a->ldq, a->ldo);
     CHECK_ARG(a->ldq >= a->heads * 64 && a->ldo >= a->heads * 64, IDMVTON_E_SHAPE, "attn_fwd: ldq/ldo < heads*64");
     AttnParams p;

@@ -49,6 +49,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 }
 #define OOB_SENTINEL 0x80000000u
 
+// Row-per-lane MFMA epilogue, 16-bit outputs: `a` = this lane's 4 columns of group 2gp (8(2gp) + 4u + j), `b` = of group 2gp+1.
+// Lanes 32..63 of a trade places with lanes 0..31 of b (v_permlane32_swap), after which every lane owns 8 CONSECUTIVE columns
+// 16gp + 8u + (0..7) of its row: one 16-byte store instead of two 8-byte ones (the tail is store-issue bound).  `dst` points at
+// column 16gp + 8u of the lane's row and must be 16-byte aligned; both lanes of a pair (l, l+32) must be active.
+template <typename V4> __device__ __forceinline__ void store_cols8(void* dst, V4 a, V4 b) {
+    static_assert(sizeof(V4) == 8, "4 x 16-bit");
+    uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+    *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -2,9 +2,5 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-for i in 1 2; do
-IDMVTON_EPILOGUE_8B=1 timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2l_bench_8B_$i.json 2> $O/r2l_bench_8B.err; echo "bench(8B) rc=$?"; python -c "
-import json,sys; d=json.loads(open('$O/r2l_bench_8B_$i.json').read().strip().splitlines()[-1]); print(d['value'], d['roofline']['step_kernel_ms'])"
-timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2l_bench_16B_$i.json 2> $O/r2l_bench_16B.err; echo "bench(16B) rc=$?"; python -c "
-import json,sys; d=json.loads(open('$O/r2l_bench_16B_$i.json').read().strip().splitlines()[-1]); print(d['value'], d['roofline']['step_kernel_ms'])"
-done
+timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "attn" 2>&1 | tail -4
+timeout 600 python tools/gpu_r2_probe.py attn > $O/r2m_probe_attn.log 2>&1; echo "attn probe rc=$?"; grep -A9 "tryon_L1\|tryon_L2\|garm_L1" $O/r2m_probe_attn.log | head -50
