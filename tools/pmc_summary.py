@@ -23,13 +23,23 @@ def main():
     pack_input_kernel and the last cfg_step_kernel of the (serial, eager) run = the launches of the denoising steps, the
     set bench.py's roofline leg covers."""
     agg, step = {}, {}
-    for d in sys.argv[1:]:
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            with open(f, newline="") as fh:
-                rd = csv.DictReader(fh)
-                cols = {c.lower(): c for c in rd.fieldnames}
-                kn, cn, cv, di = cols["kernel_name"], cols["counter_name"], cols["counter_value"], cols["dispatch_id"]
-                rows = sorted(((int(r[di]), short(r[kn]), r[cn], float(r[cv])) for r in rd), key=lambda t: t[0])
+    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    label = sys.argv[sys.argv.index("--label") + 1] if "--label" in sys.argv else None
+    for d in dirs:
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) + \
+            glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+        for f in files:
+            if f.endswith(".db"):                          # rocpd database (rocprofv3's default output format)
+                import sqlite3
+                c = sqlite3.connect(f)
+                rows = sorted(((int(did), short(kn), cn, float(v)) for did, kn, cn, v in
+                               c.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection")), key=lambda t: t[0])
+            else:
+                with open(f, newline="") as fh:
+                    rd = csv.DictReader(fh)
+                    cols = {c.lower(): c for c in rd.fieldnames}
+                    kn, cn, cv, di = cols["kernel_name"], cols["counter_name"], cols["counter_value"], cols["dispatch_id"]
+                    rows = sorted(((int(r[di]), short(r[kn]), r[cn], float(r[cv])) for r in rd), key=lambda t: t[0])
             lo = min((t[0] for t in rows if t[1] == "pack_input_kernel"), default=None)
             hi = max((t[0] for t in rows if t[1] == "cfg_step_kernel"), default=None)
             for did, k, c, v in rows:
@@ -56,6 +66,8 @@ def main():
     if "hbm_bytes_per_launch" in g:
         res["gemm_conv_bytes_per_launch"] = g["hbm_bytes_per_launch"]
         res["gemm_conv_launches_counted"] = g["FETCH_SIZE"]["dispatches"]
+    if label:
+        res["source"] = label
     json.dump(res, sys.stdout, indent=1, sort_keys=True)
 
 
