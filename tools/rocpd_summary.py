@@ -1,5 +1,7 @@
 """Summarise a rocprofv3 rocpd SQLite database (`*_results.db`) into a short text table (names truncated).
-Usage: python tools/rocpd_summary.py <results.db> [--by-grid] [--match substr]  > profiles/<name>.txt"""
+Usage: python tools/rocpd_summary.py <results.db> [--by-grid] [--match substr]  > profiles/<name>.txt
+       python tools/rocpd_summary.py <results.db> --timeline   : GPU busy / idle inside the denoising window (first pack_input ..
+       last cfg_step of the LAST pipeline call): span, union of kernel intervals, sum of durations, idle gaps by size"""
 import re
 import sqlite3
 import sys
@@ -14,8 +16,50 @@ def short(name):
     return name[:70]
 
 
+def timeline(db):
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    packs = [i for i, r in enumerate(rows) if "pack_input_kernel" in r[0]]
+    cfgs = [i for i, r in enumerate(rows) if "cfg_step_kernel" in r[0]]
+    if not packs or not cfgs:
+        print("no denoising window found"); return
+    # the last pipeline call: walk back from the last cfg_step to the pack_input that starts its run of steps
+    hi = cfgs[-1]
+    nsteps = 1
+    # contiguous run of steps: every cfg_step is followed within 50 launches by the next pack_input
+    j = len(packs) - 1
+    while j > 0 and packs[j] > cfgs[-1]:
+        j -= 1
+    lo = packs[j]
+    while j > 0 and any(packs[j - 1] < ci < packs[j] for ci in cfgs) and packs[j] - max(ci for ci in cfgs if ci < packs[j]) < 50:
+        j -= 1
+        lo = packs[j]
+        nsteps += 1
+    win = rows[lo:hi + 1]
+    t0, t1 = win[0][1], max(r[2] for r in win)
+    busy, cur_s, cur_e, gaps = 0, win[0][1], win[0][2], []
+    for _, s_, e_ in win[1:]:
+        if s_ > cur_e:
+            busy += cur_e - cur_s
+            gaps.append(s_ - cur_e)
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    busy += cur_e - cur_s
+    span, sumdur = t1 - t0, sum(r[2] - r[1] for r in win)
+    print(f"# {db}")
+    print(f"denoising window of the last call: {nsteps} steps, {len(win)} kernels, span {span / 1e6:.2f} ms = {span / 1e6 / nsteps:.2f} ms/step")
+    print(f"  GPU busy (union of kernel intervals) {busy / 1e6:.2f} ms = {100 * busy / span:.1f} % of span; idle {100 * (span - busy) / span:.1f} %")
+    print(f"  sum of kernel durations {sumdur / 1e6:.2f} ms = {sumdur / busy:.2f} x busy time (> 1: kernels of the two streams overlap)")
+    for lo_us, hi_us in ((0, 2), (2, 5), (5, 10), (10, 50), (50, 1e9)):
+        g = [x for x in gaps if lo_us * 1e3 <= x < hi_us * 1e3]
+        print(f"  idle gaps {lo_us:>3}-{hi_us if hi_us < 1e9 else 'inf':>3} us: {len(g):6d} gaps, {sum(g) / 1e6:8.3f} ms")
+
+
 def main():
     db = sys.argv[1]
+    if "--timeline" in sys.argv:
+        return timeline(db)
     by_grid = "--by-grid" in sys.argv
     match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else None
     c = sqlite3.connect(db)
