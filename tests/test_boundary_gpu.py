@@ -187,3 +187,41 @@ def test_pipeline_boundary_end_to_end():
             proc.scale = 0.0
     base0, alt0 = run(added), run(other)
     assert torch.equal(base0, alt0) and not torch.equal(base0, base1)
+
+
+def test_vae_fp16_module_survives_activations_beyond_fp16_range():
+    """the stock SDXL VAE overflows fp16 activations, which is why the reference upcasts it to fp32
+    (tryon_pipeline.py:911-930, 1868-1880).  Weights here are scaled so the first conv's outputs reach ~1e5 (> 65504): an fp16
+    module with force_upcast (the SDXL default) must still agree with the fp32 oracle -- the HIP VAE stores bf16 for it -- while
+    fp16 STORAGE (force_upcast=False) demonstrably cannot."""
+    import dataclasses
+    from idm_vton_amd import config as pc
+    from idm_vton_amd.boundary.vae import AutoencoderKL
+    from oracle import vae as ov
+    from tests import parity_utils as pu
+    vcfg = pc.VAEConfig(**pu.TINY_VAE)
+    sd = pc.random_state_dict(pc.vae_param_shapes(vcfg), 7, torch.float32, "cpu", std=0.05)
+    for k in ("encoder.conv_in.weight", "encoder.conv_in.bias", "decoder.conv_in.weight", "decoder.conv_in.bias"):
+        sd[k] = (sd[k] * 4e5).clamp(-6e4, 6e4)                  # still fp16-representable weights, activations far beyond fp16
+    sd = {k: v.half().float() for k, v in sd.items()}
+    o = ov.AutoencoderKL(ov.VAEConfig(**{f.name: getattr(vcfg, f.name) for f in dataclasses.fields(ov.VAEConfig)})).eval()
+    o.load_state_dict(sd)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    with torch.no_grad():
+        act = torch.nn.functional.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+        assert act.abs().max() > 65504, "the fixture no longer exceeds the fp16 range"
+        mean_o, _ = o.encode_moments(x)
+        dec_o = o.decode(mean_o)
+    v = AutoencoderKL(vcfg, torch_dtype=torch.float16)
+    v.load_state_dict({k: t.half() for k, t in sd.items()})
+    v = v.to(DEV)
+    assert v.config.force_upcast and v.hip_engine().dtype == torch.bfloat16
+    mean_p = v.encode(x.to(DEV)).latent_dist.mode()
+    dec_p = v.decode(mean_o.to(DEV)).sample
+    assert torch.isfinite(mean_p).all() and torch.isfinite(dec_p).all()
+    assert _rel(mean_p, mean_o) < 4e-2 and _rel(dec_p, dec_o) < 4e-2
+    v.config.force_upcast = False                               # fp16 storage: what the upcast exists to avoid
+    assert v.hip_engine().dtype == torch.float16
+    bad = v.encode(x.to(DEV)).latent_dist.mode()
+    assert (not torch.isfinite(bad).all()) or _rel(bad, mean_o) > 0.2
