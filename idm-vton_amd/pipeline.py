@@ -5,6 +5,12 @@ Per step (tryon_pipeline.py:1765-1866): pack 13-channel input -> GarmentNet -> T
 in one batch, unconditional garment half in closed form) -> fused CFG + scheduler update.  Everything step-invariant is
 computed once before the loop (time-embedding tables for every timestep, text / image-token K and V^T of all 140 attn2,
 mask / masked-image / pose latents).  Optionally the step is captured into one hipGraph and replayed.
+
+GarmentNet's inputs (cloth latent, cloth text, timestep) never depend on the latents, so the loop runs it for `garment_steps`
+CONSECUTIVE TIMESTEPS IN ONE BATCH (batch = images x timesteps, each batch element with its own time embedding): the same
+per-(image, timestep) arithmetic as the reference's one call per step (:1781-1787), but its GEMMs see 2-3x the rows (M = 1536
+-> 4608 at the 1280-channel level), which is where the small-M projections of the loop lose their efficiency.  A "block" is
+that GarmentNet batch plus the `garment_steps` TryonNet steps that consume its features.
 """
 import torch
 
@@ -14,9 +20,9 @@ from .scheduler import StepScheduler
 
 def _copy_state(dst, src):
     """Copy every tensor the captured step reads (latents, conditioning, K/V^T caches) into the graph's buffers."""
-    for k in ("latents", "cond", "cloth"):
+    for k in ("latents", "cond", "cloth", "cloth_k"):
         dst[k].copy_(src[k])
-    for ck in ("ctx_t", "ctx_g"):
+    for ck in ("ctx_t", "ctx_g", "ctx_gk"):
         for p, ent in src[ck]["kv"].items():
             for name, t in ent.items():
                 dst[ck]["kv"][p][name].copy_(t)
@@ -28,6 +34,7 @@ class TryonEngine:
         self.dtype, self.device = dtype, torch.device(device)
         self._graphs = {}
         self._side = None
+        self.garment_steps = 6                               # timesteps per GarmentNet batch (see the module docstring)
 
     # -------------------------------------------------------------------------------------------- preparation
     @torch.no_grad()
@@ -68,10 +75,20 @@ class TryonEngine:
         ctx_g = self.unet_encoder.encode_context(text_embeds_cloth.to(dev))
         temb_t = self.unet.time_embeddings(timesteps, 2 * B, dict(text_embeds=add_text, time_ids=time_ids))
         temb_g = self.unet_encoder.time_embeddings(timesteps, B)
+        # GarmentNet over k consecutive timesteps per batch: batch index = j*B + b (timestep-major), the last block padded by
+        # repeating the final timestep (its extra rows are never read)
+        n = len(timesteps)
+        k = max(1, min(self.garment_steps, n))
+        blocks = [(s0, min(k, n - s0)) for s0 in range(0, n, k)]
+        tidx = torch.tensor([[min(s0 + j, n - 1) for j in range(k)] for s0, _ in blocks], device=dev)
+        temb_gk = temb_g[tidx].reshape(len(blocks), k * B, -1).contiguous()
+        cloth_k = cloth_nhwc.repeat(k, 1, 1).contiguous()
+        ctx_gk = ctx_g if k == 1 else self.unet_encoder.encode_context(text_embeds_cloth.to(dev).repeat(k, 1, 1))
         coef = torch.tensor([list(sched.coeffs(t)) + [guidance_scale] for t in timesteps], dtype=torch.float32, device=dev)
         steps_noise = f32(noise["steps"]) if noise.get("steps") is not None and scheduler == "ddpm" else None
         return dict(B=B, h=h, w=w, timesteps=timesteps, latents=latents.contiguous(), cond=cond, cloth=cloth_nhwc,
                     ctx_t=ctx_t, ctx_g=ctx_g, temb_t=temb_t, temb_g=temb_g, coef=coef, steps_noise=steps_noise,
+                    k=k, blocks=blocks, temb_gk=temb_gk, cloth_k=cloth_k, ctx_gk=ctx_gk,
                     x_in=torch.empty(2 * B, h * w, self.unet.cin_pad, dtype=dt, device=dev),
                     trace=dict(masked_lat=masked_lat, pose_lat=pose_lat, cloth_lat=cloth_lat, image_embeds=image_embeds))
 
@@ -86,151 +103,172 @@ class TryonEngine:
         ops.cfg_step(eps, st["latents"], noise, coef)                                      # :1814-1823
         return eps
 
-    # GarmentNet's inputs (cloth latent, cloth text, timestep) do not depend on the latents, so GarmentNet for step i+1 --
-    # and the attn1 K / V^T projections of its 70 features with TryonNet's weights -- run on a second HIP stream while
-    # TryonNet runs step i.  Two feature sets alternate; there is no other coupling between the streams.
-    def _garment_side(self, st, temb_g, fset):
-        B, h, w = st["B"], st["h"], st["w"]
-        self.unet_encoder.forward(st["cloth"], temb_g, st["ctx_g"], B, h, w, feats_buf=fset["feats"])      # :1787
+    # ---- blocks: one GarmentNet batch over k timesteps + the k TryonNet steps that consume it ------------------------------
+    # The GarmentNet batch of block b+1 -- and the attn1 K / V^T projections of its features with TryonNet's weights -- can run on a
+    # second HIP stream while TryonNet runs the steps of block b.  Two feature sets alternate; there is no other coupling.
+    def _garment_side(self, st, temb_gk, fset):
+        B, h, w, k = st["B"], st["h"], st["w"], st["k"]
+        self.unet_encoder.forward(st["cloth_k"], temb_gk, st["ctx_gk"], k * B, h, w, feats_buf=fset["feats"])   # :1787, k timesteps
         self.unet.project_garment_kv(fset["feats"], out=fset["kv"])
 
-    def _tryon_main(self, st, temb_t, coef, noise, fset):
+    def _tryon_main(self, st, temb_t, coef, noise, kv_j):
         B, h, w = st["B"], st["h"], st["w"]
         ops.pack_input(st["latents"], st["cond"], st["x_in"])                              # :1769,1777
-        eps, _ = self.unet.forward(st["x_in"], temb_t, st["ctx_t"], 2 * B, h, w, garment_kv=fset["kv"])  # :1796-1808
+        eps, _ = self.unet.forward(st["x_in"], temb_t, st["ctx_t"], 2 * B, h, w, garment_kv=kv_j)        # :1796-1808
         ops.cfg_step(eps, st["latents"], noise, coef)                                      # :1814-1823
         return eps
 
-    def _feature_sets(self, st, temb_g0):
-        """Two persistent {70 features, 70 (K, V^T)} sets; set 0 is filled for the first step on the current stream."""
-        B, h, w = st["B"], st["h"], st["w"]
-        _, feats = self.unet_encoder.forward(st["cloth"], temb_g0, st["ctx_g"], B, h, w)
-        kv = self.unet.project_garment_kv(feats)
-        s0 = dict(feats=feats, kv=kv)
-        s1 = dict(feats=[torch.empty_like(f) for f in feats], kv=[(torch.empty_like(k), torch.empty_like(v)) for k, v in kv])
-        return [s0, s1]
+    def _new_set(self, st, like=None):
+        """A persistent {70 features, 70 (K, V^T)} set for k timesteps + per-timestep views of its K / V^T."""
+        B, h, w, k = st["B"], st["h"], st["w"], st["k"]
+        if like is None:
+            _, feats = self.unet_encoder.forward(st["cloth_k"], st["temb_gk"][0], st["ctx_gk"], k * B, h, w)
+            kv = self.unet.project_garment_kv(feats)
+        else:
+            feats = [torch.empty_like(f) for f in like["feats"]]
+            kv = [(torch.empty_like(kk), torch.empty_like(vv)) for kk, vv in like["kv"]]
+        per_step = []
+        for j in range(k):
+            per_step.append([(kk[j * B * (kk.shape[0] // (k * B)):(j + 1) * B * (kk.shape[0] // (k * B))], vv[j * B:(j + 1) * B]) for kk, vv in kv])
+        return dict(feats=feats, kv=kv, step=per_step)
+
+    def _noise(self, st, i):
+        return st["steps_noise"][i] if st["steps_noise"] is not None else None
+
+    def _denoise_serial_eager(self, st, trace=None):
+        fset = None
+        for bi, (s0, c) in enumerate(st["blocks"]):
+            if fset is None:
+                fset = self._new_set(st)                                   # runs block 0's GarmentNet batch
+            else:
+                self._garment_side(st, st["temb_gk"][bi], fset)
+            for j in range(c):
+                i = s0 + j
+                self._tryon_main(st, st["temb_t"][i], st["coef"][i], self._noise(st, i), fset["step"][j])
+                if trace is not None:
+                    trace.setdefault("step_latents", []).append(st["latents"].clone())
+        return st["latents"]
 
     def _denoise_overlap_eager(self, st):
-        n = len(st["timesteps"])
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
         side = self._side
-        sets = self._feature_sets(st, st["temb_g"][0])
+        s0set = self._new_set(st)
+        sets = [s0set, self._new_set(st, like=s0set)]
         ready = [torch.cuda.Event(), torch.cuda.Event()]
         free = [torch.cuda.Event(), torch.cuda.Event()]
         side.wait_stream(main)                                       # prepare()'s tensors and set 0 are complete
-        for i in range(n):
-            cur, nxt = i & 1, (i + 1) & 1
-            if i + 1 < n:
+        nb = len(st["blocks"])
+        for bi, (s0, c) in enumerate(st["blocks"]):
+            cur, nxt = bi & 1, (bi + 1) & 1
+            if bi + 1 < nb:
                 with torch.cuda.stream(side):
-                    if i >= 1:
-                        side.wait_event(free[nxt])                   # TryonNet step i-1 is done reading set nxt
-                    self._garment_side(st, st["temb_g"][i + 1], sets[nxt])
+                    if bi >= 1:
+                        side.wait_event(free[nxt])                   # TryonNet block bi-1 is done reading set nxt
+                    self._garment_side(st, st["temb_gk"][bi + 1], sets[nxt])
                     ready[nxt].record(side)
-            if i >= 1:
+            if bi >= 1:
                 main.wait_event(ready[cur])
-            nz = st["steps_noise"][i] if st["steps_noise"] is not None else None
-            self._tryon_main(st, st["temb_t"][i], st["coef"][i], nz, sets[cur])
+            for j in range(c):
+                i = s0 + j
+                self._tryon_main(st, st["temb_t"][i], st["coef"][i], self._noise(st, i), sets[cur]["step"][j])
             free[cur].record(main)
         main.wait_stream(side)
         return st["latents"]
 
-    def _denoise_overlap_graph(self, st):
-        """hipGraph form of the two-stream loop: per parity one graph with two parallel branches {TryonNet step i on set p |
-        GarmentNet step i+1 into set p^1}, plus a TryonNet-only graph for the last step.  Consecutive graph launches are
-        ordered on the launching stream, which is exactly the dependency the two sets need.  Captures use
-        capture_error_mode="thread_local": with torch.distributed / RCCL initialised a watchdog thread polls events, which
-        the default global mode would treat as a capture violation."""
-        n = len(st["timesteps"])
+    def _graph_state(self, st, overlap):
+        """Persistent buffers + captured graphs for one shape.  Graphs: ('pair', parity, c) = {c TryonNet steps on set p |
+        GarmentNet batch into set p^1} as two parallel branches (overlap) or in sequence into the same set (serial: ('block', c));
+        ('last', parity, c) = c TryonNet steps only.  Consecutive graph launches are ordered on the launching stream, which is exactly
+        the dependency the two sets need.  Captures use capture_error_mode="thread_local": with torch.distributed / RCCL initialised a
+        watchdog thread polls events, which the default global mode would treat as a capture violation."""
         has_noise = st["steps_noise"] is not None
-        key = (st["B"], st["h"], st["w"], has_noise, "overlap")
-        if key not in self._graphs:
-            tt, tg, cf = st["temb_t"][0].clone(), st["temb_g"][0].clone(), st["coef"][0].clone()
-            nz = st["steps_noise"][0].clone() if has_noise else None
-            saved = st["latents"].clone()
-            warm = torch.cuda.Stream()
-            warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm):                            # warm-up off the default stream (allocator, lazy init)
-                sets = self._feature_sets(st, tg)
-                self._garment_side(st, tg, sets[1])
-                self._tryon_main(st, tt, cf, nz, sets[0])
-            torch.cuda.current_stream().wait_stream(warm)
-            torch.cuda.synchronize()
-            st["latents"].copy_(saved)
-            side = torch.cuda.Stream()
-            pair, last = {}, {}
-            for par in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    cap = torch.cuda.current_stream()
-                    side.wait_stream(cap)                            # fork
-                    with torch.cuda.stream(side):
-                        self._garment_side(st, tg, sets[par ^ 1])
-                    self._tryon_main(st, tt, cf, nz, sets[par])
-                    cap.wait_stream(side)                            # join
-                pair[par] = g
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                    self._tryon_main(st, tt, cf, nz, sets[par])
-                last[par] = g2
-            st["latents"].copy_(saved)
-            self._graphs[key] = dict(st=st, tt=tt, tg=tg, cf=cf, nz=nz, sets=sets, pair=pair, last=last)
-        G = self._graphs[key]
-        sst, tt, tg, cf, nz = G["st"], G["tt"], G["tg"], G["cf"], G["nz"]
+        key = (st["B"], st["h"], st["w"], st["k"], has_noise, "overlap" if overlap else "serial")
+        if key in self._graphs:
+            return self._graphs[key]
+        k = st["k"]
+        tt = [st["temb_t"][0].clone() for _ in range(k)]
+        cf = [st["coef"][0].clone() for _ in range(k)]
+        nz = [st["steps_noise"][0].clone() if has_noise else None for _ in range(k)]
+        tgk = st["temb_gk"][0].clone()
+        saved = st["latents"].clone()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):                                # warm-up off the default stream (allocator, lazy init)
+            s0set = self._new_set(st)
+            sets = [s0set, self._new_set(st, like=s0set)] if overlap else [s0set]
+            self._garment_side(st, tgk, sets[-1])
+            self._tryon_main(st, tt[0], cf[0], nz[0], sets[0]["step"][0])
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        st["latents"].copy_(saved)
+        G = dict(st=st, tt=tt, cf=cf, nz=nz, tgk=tgk, sets=sets, graphs={}, side=torch.cuda.Stream(), saved=saved)
+        self._graphs[key] = G
+        return G
+
+    def _graph(self, G, kind, par, c):
+        """Capture on first use: kind 'pair' (overlap: TryonNet x c on set par | GarmentNet into set par^1), 'block' (serial:
+        GarmentNet into set 0, then TryonNet x c), 'last' (TryonNet x c on set par)."""
+        gk = (kind, par, c)
+        if gk in G["graphs"]:
+            return G["graphs"][gk]
+        st, side = G["st"], G["side"]
+        keep = st["latents"].clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            if kind == "pair":
+                cap = torch.cuda.current_stream()
+                side.wait_stream(cap)                                # fork
+                with torch.cuda.stream(side):
+                    self._garment_side(st, G["tgk"], G["sets"][par ^ 1])
+            elif kind == "block":
+                self._garment_side(st, G["tgk"], G["sets"][0])
+            for j in range(c):
+                self._tryon_main(st, G["tt"][j], G["cf"][j], G["nz"][j], G["sets"][par]["step"][j])
+            if kind == "pair":
+                cap.wait_stream(side)                                # join
+        st["latents"].copy_(keep)                                    # capture does not execute, but keep the state explicit
+        G["graphs"][gk] = g
+        return g
+
+    def _denoise_graph(self, st, overlap, trace=None):
+        G = self._graph_state(st, overlap)
+        sst = G["st"]
         if sst is not st:
             _copy_state(sst, st)                                                           # new call -> persistent buffers
-        self._garment_side(sst, st["temb_g"][0].contiguous(), G["sets"][0])               # step 0's features (eager, once)
-        for i in range(n):
-            tt.copy_(st["temb_t"][i]); cf.copy_(st["coef"][i])
-            if nz is not None:
-                nz.copy_(st["steps_noise"][i])
-            if i + 1 < n:
-                tg.copy_(st["temb_g"][i + 1])
-                G["pair"][i & 1].replay()
+        blocks, nb = st["blocks"], len(st["blocks"])
+
+        def load(s0, c):
+            for j in range(c):
+                i = s0 + j
+                G["tt"][j].copy_(st["temb_t"][i]); G["cf"][j].copy_(st["coef"][i])
+                if G["nz"][j] is not None:
+                    G["nz"][j].copy_(st["steps_noise"][i])
+
+        if overlap:
+            self._garment_side(sst, st["temb_gk"][0].contiguous(), G["sets"][0])          # block 0's features (eager, once)
+        for bi, (s0, c) in enumerate(blocks):
+            load(s0, c)
+            if overlap:
+                if bi + 1 < nb:
+                    G["tgk"].copy_(st["temb_gk"][bi + 1])
+                    self._graph(G, "pair", bi & 1, c).replay()
+                else:
+                    self._graph(G, "last", bi & 1, c).replay()
             else:
-                G["last"][i & 1].replay()
+                G["tgk"].copy_(st["temb_gk"][bi])
+                self._graph(G, "block", 0, c).replay()
+            if trace is not None:
+                trace.setdefault("block_latents", []).append(sst["latents"].clone())
         return sst["latents"]
 
     @torch.no_grad()
     def denoise(self, st, use_graph=False, trace=None, overlap=False):
-        n = len(st["timesteps"])
-        if overlap:
-            return self._denoise_overlap_graph(st) if use_graph else self._denoise_overlap_eager(st)
-        if not use_graph:
-            for i in range(n):
-                nz = st["steps_noise"][i] if st["steps_noise"] is not None else None
-                eps = self._step(st, st["temb_t"][i], st["temb_g"][i], st["coef"][i], nz)
-                if trace is not None:
-                    trace.setdefault("step_latents", []).append(st["latents"].clone())
-            return st["latents"]
-        # ---- hipGraph: one step captured ONCE per shape on persistent buffers, replayed n times per call ----
-        key = (st["B"], st["h"], st["w"], n, st["steps_noise"] is not None)
-        if key not in self._graphs:
-            tt, tg, cf = st["temb_t"][0].clone(), st["temb_g"][0].clone(), st["coef"][0].clone()
-            nz = st["steps_noise"][0].clone() if st["steps_noise"] is not None else None
-            saved = st["latents"].clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self._step(st, tt, tg, cf, nz)                                             # warm-up (allocator, lazy init)
-            torch.cuda.current_stream().wait_stream(side)
-            st["latents"].copy_(saved)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                self._step(st, tt, tg, cf, nz)
-            self._graphs[key] = (graph, st, tt, tg, cf, nz)
-        graph, sst, tt, tg, cf, nz = self._graphs[key]
-        if sst is not st:
-            _copy_state(sst, st)                                                           # new call -> persistent buffers
-        for i in range(n):
-            tt.copy_(st["temb_t"][i]); tg.copy_(st["temb_g"][i]); cf.copy_(st["coef"][i])
-            if nz is not None:
-                nz.copy_(st["steps_noise"][i])
-            graph.replay()
-            if trace is not None:
-                trace.setdefault("step_latents", []).append(sst["latents"].clone())
-        return sst["latents"]
+        """The loop.  Four execution forms with bit-identical results: {serial, two-stream overlap} x {eager, hipGraph replay}."""
+        if use_graph:
+            return self._denoise_graph(st, overlap, trace)
+        return self._denoise_overlap_eager(st) if overlap else self._denoise_serial_eager(st, trace)
 
     @torch.no_grad()
     def decode(self, latents):

@@ -60,6 +60,32 @@ def test_serial_loop_is_bit_reproducible():
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+def test_garment_timestep_batching_does_not_change_results():
+    """GarmentNet runs for `garment_steps` consecutive timesteps in one batch (idm_vton_amd/pipeline.py): per (image, timestep)
+    the arithmetic is the reference's one call per step (tryon_pipeline.py:1781-1787).  Every batching factor -- including blocks
+    that do not divide the step count -- must give the latents of the one-call-per-step form, in all four execution forms."""
+    from idm_vton_amd.pipeline import TryonEngine
+    from tests import parity_utils as pu
+    dt = torch.float16
+    m = pu.build("tiny", dt, "cuda")
+    p_t, p_g, p_v, p_r = m["product"]
+    inp = pu.make_inputs(2, 128, 128, m["xd"], m["pooled"], m["enc_dim"], 5, dt)
+    outs = {}
+    for k in (1, 2, 3, 5, 8):
+        eng = TryonEngine(p_t, p_g, p_v, p_r, dt, "cuda")
+        eng.garment_steps = k
+        for kw in (dict(), dict(use_graph=True), dict(overlap=True), dict(use_graph=True, overlap=True)):
+            st = eng.prepare(num_inference_steps=5, guidance_scale=2.0, scheduler="ddpm", **inp)
+            outs[(k, tuple(sorted(kw)))] = eng.denoise(st, **kw).clone()
+    ref = outs[(1, ())]
+    for key, o in outs.items():
+        if key[0] == 1:
+            assert torch.equal(o, ref), key                      # execution forms are bit-identical
+        assert torch.equal(o, outs[(key[0], ())]), key           # ... for every batching factor
+        # across factors only GroupNorm's partial-sum blocking (a function of the batch size) may differ, in the last bit
+        assert pu.relerr(o, ref) < 1e-3, (key, pu.relerr(o, ref))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 def test_mid_pipeline_parity(dtype):
     """The wider configuration of tests/parity_utils.py (320/640/1280 channels, 5/10/20 heads: the SDXL widths, 128x128 GEMM

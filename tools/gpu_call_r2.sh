@@ -2,12 +2,10 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace -d $O/prof_tl_default -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/bench_tl_default.json 2> $O/prof_tl_default.err; echo "prof default rc=$?"
-timeout 600 rocprofv3 --kernel-trace -d $O/prof_tl_serial -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-overlap > $O/bench_tl_serial.json 2> $O/prof_tl_serial.err; echo "prof serial rc=$?"
-cd $R
-for d in prof_tl_default prof_tl_serial; do
-  db=$(find $O/$d -name "*.db" | head -1)
-  python tools/rocpd_summary.py $db --timeline | tee $O/${d}_timeline.txt
-done
-find $O/prof_tl_default $O/prof_tl_serial -name "*.db" -size +20M -delete 2>/dev/null
+rm -f $O/tune_gfx950.json
+timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/r2p_bench_oldtune.json 2> $O/r2p_bench_oldtune.err; echo "old tune rc=$? $(python -c "
+import json; d=json.loads(open('$O/r2p_bench_oldtune.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"
+timeout 1500 python tools/gpu_tune.py > $O/r2p_tune.log 2>&1; echo "tune rc=$?"; tail -3 $O/r2p_tune.log
+[ -f $O/tune_gfx950.json ] && cp $O/tune_gfx950.json $R/idm-vton_amd/tune_gfx950.json
+timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2p_bench_tuned.json 2> $O/r2p_bench_tuned.err; echo "tuned rc=$? $(python -c "
+import json; d=json.loads(open('$O/r2p_bench_tuned.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['step_kernel_ms'], d['roofline']['launches_per_denoise_step'])")"

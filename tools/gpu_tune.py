@@ -57,7 +57,10 @@ def main():
     with torch.no_grad():
         st = engine.prepare(num_inference_steps=30, guidance_scale=2.0, scheduler="ddim", **inp)
         n_prep = len(ops.RECORD)
-        engine._step(st, st["temb_t"][0], st["temb_g"][0], st["coef"][0], None)
+        k = st["k"]                                      # one block of the loop: GarmentNet over k timesteps + k TryonNet steps
+        fset = engine._new_set(st)
+        for j in range(k):
+            engine._tryon_main(st, st["temb_t"][j], st["coef"][j], None, fset["step"][j])
         n_step = len(ops.RECORD)
         engine.decode(st["latents"])
     rec, ops.RECORD = ops.RECORD, None
@@ -65,7 +68,7 @@ def main():
 
     uniq = {}
     for i, (kind, key, a, keep) in enumerate(rec):
-        w = 30 if n_prep <= i < n_step else 1            # loop launches run 30x per call
+        w = 30.0 / k if n_prep <= i < n_step else 1      # a block's launches run 30/k times per call
         u = uniq.setdefault((kind, key), dict(kind=kind, key=key, a=a, keep=keep, weight=0))
         u["weight"] += w
     print(f"{len(rec)} launches recorded, {len(uniq)} unique signatures", flush=True)
@@ -158,7 +161,7 @@ def main():
         tot_def += t_def * u["weight"]
         tot_best += best_t * u["weight"]
         report.append(row)
-        print(f"{kind:4s} {key:44s} x{u['weight']:<4d} default {t_def:8.1f}us  best {best_name:10s} {best_t:8.1f}us  " +
+        print(f"{kind:4s} {key:44s} x{u['weight']:<6.1f} default {t_def:8.1f}us  best {best_name:10s} {best_t:8.1f}us  " +
               " ".join(f"{k}={v}" for k, v in row["cands"].items()), flush=True)
 
     print(f"weighted kernel time per call: default {tot_def / 1e3:.1f} ms -> tuned {tot_best / 1e3:.1f} ms", flush=True)
