@@ -2,10 +2,9 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-rm -f $O/tune_gfx950.json
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/r2p_bench_oldtune.json 2> $O/r2p_bench_oldtune.err; echo "old tune rc=$? $(python -c "
-import json; d=json.loads(open('$O/r2p_bench_oldtune.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"
-timeout 1500 python tools/gpu_tune.py > $O/r2p_tune.log 2>&1; echo "tune rc=$?"; tail -3 $O/r2p_tune.log
-[ -f $O/tune_gfx950.json ] && cp $O/tune_gfx950.json $R/idm-vton_amd/tune_gfx950.json
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2p_bench_tuned.json 2> $O/r2p_bench_tuned.err; echo "tuned rc=$? $(python -c "
-import json; d=json.loads(open('$O/r2p_bench_tuned.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['step_kernel_ms'], d['roofline']['launches_per_denoise_step'])")"
+for mode in "" "--no-graph" "--no-overlap" "--no-overlap --no-graph"; do
+  tag=$(echo "default$mode" | tr -d ' ')
+  timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline $mode > $O/r2q_bench_$tag.json 2> $O/r2q_bench_$tag.err; echo "$tag rc=$? $(python -c "
+import json; d=json.loads(open('$O/r2q_bench_$tag.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"
+done
+bash tools/gpu_pmc_traffic.sh "round 2 final kernels: 16-byte epilogue, GarmentNet batched over 6 timesteps (rocprofv3 --pmc over the serial eager bench command, 6 denoising steps = one block)"
