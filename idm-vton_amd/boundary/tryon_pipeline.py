@@ -11,7 +11,9 @@ they are transformers CLIP towers living on the GPU their forward is executed by
 3 VAE encodes, Resampler, hoisted K/V + embedding tables, the denoising loop (GarmentNet || TryonNet on two streams,
 hipGraph replay) and the decode.  RNG draws follow the reference's order with the caller's generator.
 
-Loud differences: guidance_scale <= 1 (no CFG), strength != 1.0, `padding_mask_crop`, `masked_image_latents=`, `timesteps=`,
+guidance_scale <= 1 (no CFG) runs the batched step with guidance 1 (the conditional prediction to one fp32 rounding, at the cost of
+the unused half); strength < 1 starts from the noised image latents as the reference does.
+Loud differences: `padding_mask_crop`, `masked_image_latents=`, `timesteps=`,
 `denoising_start/end`, `guidance_rescale`, `cross_attention_kwargs`, step callbacks, `num_images_per_prompt != 1` and
 schedulers other than DDPM/DDIM raise NotImplementedError: the reference scripts use none of them.
 """
@@ -348,13 +350,13 @@ class StableDiffusionXLInpaintPipeline:
                           negative_prompt, negative_prompt_2, prompt_embeds, negative_prompt_embeds,
                           callback_on_step_end_tensor_inputs, padding_mask_crop)
         self._guidance_scale = guidance_scale
-        if not self.do_classifier_free_guidance:
-            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance): the HIP engine batches the two CFG halves")
-        if strength != 1.0:
-            # reference :1561-1567,1610-1630: strength < 1 starts from the noised image latents and skips the first
-            # int(n*(1-strength)) steps (the signature default 0.9999 already drops one); only the strength = 1.0 path that
-            # inference.py:404 and gradio_demo/app.py:225 take (pure-noise start, all n steps) is implemented
-            raise NotImplementedError(f"strength={strength}: only strength=1.0 (the value the try-on scripts pass) is supported")
+        cfg = self.do_classifier_free_guidance              # guidance_scale <= 1: the engine runs its batched step with guidance 1
+        # strength < 1 (reference :987-995, 883-893): the last int(n*strength) timesteps, from the noised image latents (the signature
+        # default 0.9999 already drops one step; inference.py:404 and gradio_demo/app.py:225 pass 1.0)
+        n_exec = min(int(num_inference_steps * strength), num_inference_steps)
+        if n_exec < 1:                                      # :1568-1572
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of pipeline"
+                             f"steps is {n_exec} which is < 1 and not appropriate for this pipeline.")
         kind = {DDPMScheduler: "ddpm", DDIMScheduler: "ddim"}.get(type(self.scheduler))
         if kind is None:
             kind = {"DDPMScheduler": "ddpm", "DDIMScheduler": "ddim"}.get(type(self.scheduler).__name__)
@@ -366,11 +368,13 @@ class StableDiffusionXLInpaintPipeline:
         eng = self.hip_engine()
         device = eng.device
         (prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds) = self.encode_prompt(
-            prompt=prompt, prompt_2=prompt_2, device=device, num_images_per_prompt=1, do_classifier_free_guidance=True,
+            prompt=prompt, prompt_2=prompt_2, device=device, num_images_per_prompt=1, do_classifier_free_guidance=cfg,
             negative_prompt=negative_prompt, negative_prompt_2=negative_prompt_2, prompt_embeds=prompt_embeds,
             negative_prompt_embeds=negative_prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
             negative_pooled_prompt_embeds=negative_pooled_prompt_embeds)                         # :1541
 
+        if not cfg:                                         # :1710-1711 never read them without CFG
+            negative_prompt_embeds = negative_pooled_prompt_embeds = None
         img = _to_tensor_image(image, "image")
         msk = _to_tensor_image(mask_image, "mask_image")
         if msk.shape[1] != 1:
@@ -393,19 +397,22 @@ class StableDiffusionXLInpaintPipeline:
         # initial latents: prompt_embeds.dtype (:1599-1610 -> prepare_latents :889); VAE posterior samples: fp32, the VAE being
         # upcast (:913-915, DiagonalGaussianDistribution.sample); DDPM variance noise: the model output's dtype (DDPMScheduler.step).
         shape = (B, 4, h, w)
+        # strength < 1 and no `latents=`: the init image is encoded first (prepare_latents :883-886 -> posterior draw), then the noise
+        n_img = _randn(shape, generator, device, torch.float32) if (strength != 1.0 and latents is None) else None
         n_lat = latents.to(device).float() if latents is not None else _randn(shape, generator, device, prompt_embeds.dtype)
         n_masked, n_pose, n_cloth = (_randn(shape, generator, device, torch.float32), _randn(shape, None, device, torch.float32),
                                      _randn(shape, generator, device, torch.float32))
         steps_noise = None
         if kind == "ddpm":
-            steps_noise = torch.stack([_randn(shape, generator, device, eng.dtype) for _ in range(num_inference_steps)])
+            steps_noise = torch.stack([_randn(shape, generator, device, eng.dtype) for _ in range(n_exec)])
         image_states = self.prepare_ip_adapter_image_embeds(ip_adapter_image, device, 1)        # :1720-1723
 
         lat = eng(image=img, mask_image=msk, pose_img=pose, cloth=clo, prompt_embeds=prompt_embeds,
                   negative_prompt_embeds=negative_prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
                   negative_pooled_prompt_embeds=negative_pooled_prompt_embeds, text_embeds_cloth=text_embeds_cloth,
-                  noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=steps_noise),
+                  noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=steps_noise, image=n_img),
                   num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, ip_hidden_states=image_states,
+                  strength=strength, image_dtype=prompt_embeds.dtype,
                   scheduler=kind, height=height, width=width, return_latents=True, use_graph=self.use_graph,
                   overlap=self.overlap)
         if output_type == "latent":

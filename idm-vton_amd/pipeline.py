@@ -40,9 +40,15 @@ class TryonEngine:
     @torch.no_grad()
     def prepare(self, *, image, mask_image, pose_img, cloth, prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds,
                 negative_pooled_prompt_embeds, text_embeds_cloth, noise, num_inference_steps, guidance_scale,
-                ip_hidden_states=None, image_embeds=None, scheduler="ddpm", height=None, width=None):
+                ip_hidden_states=None, image_embeds=None, scheduler="ddpm", height=None, width=None, strength=1.0,
+                image_dtype=None):
         """Everything before the loop (tryon_pipeline.py:1495-1762).  image in [0,1]; pose_img / cloth in [-1,1];
-        noise: dict(latents, masked, pose, cloth [B,4,h,w] fp32; steps [n,B,4,h,w] fp32 or None) -- RNG order SURVEY A.4."""
+        noise: dict(latents, masked, pose, cloth [B,4,h,w] fp32; steps [n,B,4,h,w] fp32 or None; image [B,4,h,w] when strength < 1)
+        -- RNG order SURVEY A.4.
+        strength < 1 (:987-995, 883-893): the last int(n*strength) timesteps, starting from add_noise(encode(image), noise, t_0).
+        guidance_scale <= 1 (:440-442: no classifier-free guidance): the reference runs the conditional branch alone; here the
+        batched step runs with guidance 1 -- u + 1*(t - u) = t to one fp32 rounding -- so negative_* may be None and
+        ip_hidden_states / image_embeds may hold the B conditional rows only."""
         dev, dt = self.device, self.dtype
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
         image, mask_image, pose_img, cloth = f32(image), f32(mask_image), f32(pose_img), f32(cloth)
@@ -51,12 +57,32 @@ class TryonEngine:
         W = width or image.shape[-1]
         h, w = H // 8, W // 8
         sched = StepScheduler(scheduler)
-        timesteps = sched.set_timesteps(num_inference_steps)                               # :1561-1567
+        timesteps = sched.set_timesteps(num_inference_steps)                               # :1561
+        init_t = min(int(num_inference_steps * strength), num_inference_steps)             # get_timesteps :987-995
+        timesteps = timesteps[max(num_inference_steps - init_t, 0):]
+        if len(timesteps) < 1:                                                             # :1568-1572
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of pipeline"
+                             f"steps is {len(timesteps)} which is < 1 and not appropriate for this pipeline.")
+        if guidance_scale <= 1:                                                            # no CFG: see the docstring
+            guidance_scale = 1.0
+            if negative_prompt_embeds is None:
+                negative_prompt_embeds = torch.zeros_like(prompt_embeds)
+            if negative_pooled_prompt_embeds is None:
+                negative_pooled_prompt_embeds = torch.zeros_like(pooled_prompt_embeds)
+            if ip_hidden_states is not None and ip_hidden_states.shape[0] == B:
+                ip_hidden_states = torch.cat([torch.zeros_like(ip_hidden_states), ip_hidden_states])
+            if image_embeds is not None and image_embeds.shape[0] == B:
+                image_embeds = torch.cat([torch.zeros_like(image_embeds), image_embeds])
 
         init_image = 2.0 * image - 1.0                                                     # preprocess :1588-1591
         mask = (mask_image >= 0.5).float()                                                 # mask_processor :1593-1595
         masked_image = init_image * (mask < 0.5)                                           # :1602
-        latents = f32(noise["latents"]) * sched.init_noise_sigma                           # :889-893
+        if strength == 1.0 or noise.get("image") is None:
+            latents = f32(noise["latents"]) * sched.init_noise_sigma                       # :889-893
+        else:                                                                              # image + noise start (:883-891)
+            src = init_image if image_dtype is None else init_image.to(image_dtype).float()    # prepare_latents casts the image (:884)
+            ab = float(sched.alphas_cumprod[int(timesteps[0])])
+            latents = ab ** 0.5 * self.vae.encode_sample(src, f32(noise["image"])) + (1.0 - ab) ** 0.5 * f32(noise["latents"])
         mask_l = torch.nn.functional.interpolate(mask, size=(h, w))                        # :939-941
         masked_lat = self.vae.encode_sample(masked_image, f32(noise["masked"]))            # :964
         pose_lat = self.vae.encode_sample(pose_img, f32(noise["pose"]))                    # :1644-1647

@@ -127,6 +127,9 @@ def pipeline_fixture(t, pc, ref_t, ref_g):
         def scale_model_input(self, sample, timestep=None):
             return sample
 
+        def add_noise(self, original_samples, noise, timesteps):
+            return self.s.add_noise(original_samples, noise, int(timesteps.reshape(-1)[0]))
+
         def step(self, model_output, timestep, sample, generator=None, return_dict=True):
             noise = None
             if int(timestep) > 0:                        # diffusers DDPMScheduler.step: variance noise drawn only for t > 0
@@ -157,33 +160,42 @@ def pipeline_fixture(t, pc, ref_t, ref_g):
     inp = dict(image=torch.rand(B, 3, H, W, generator=g), mask_image=mask, pose_img=r(B, 3, H, W).clamp(-1, 1), cloth=r(B, 3, H, W).clamp(-1, 1),
                prompt_embeds=r(B, 77, 128), negative_prompt_embeds=r(B, 77, 128), pooled_prompt_embeds=r(B, 64),
                negative_pooled_prompt_embeds=r(B, 64), text_embeds_cloth=r(B, 77, 128), clip_pixels=r(B, 3, 224, 224))
-    tu.RECORD = []
-    torch.manual_seed(4242)                               # the pose posterior is drawn from the GLOBAL generator (:1646)
-    step_lat = []
-    orig_step = pipe.scheduler.step
-
-    def rec_step(*a, **k):
-        out = orig_step(*a, **k)
-        step_lat.append(out[0].clone())
-        return out
-    pipe.scheduler.step = rec_step
-    images = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
-                  pooled_prompt_embeds=inp["pooled_prompt_embeds"], negative_pooled_prompt_embeds=inp["negative_pooled_prompt_embeds"],
-                  num_inference_steps=steps, generator=torch.Generator().manual_seed(7), strength=1.0, pose_img=inp["pose_img"],
-                  text_embeds_cloth=inp["text_embeds_cloth"], cloth=inp["cloth"], mask_image=inp["mask_image"], image=inp["image"],
-                  height=H, width=W, guidance_scale=2.0, ip_adapter_image=inp["clip_pixels"], output_type="pt")[0]
-    draws, tu.RECORD = tu.RECORD, None
-    assert len(draws) == 4 + (steps - 1) or len(draws) == 4 + steps, len(draws)
-    for k, v in inp.items():
-        t[f"pipe.in.{k}"] = v
-    for i, d in enumerate(draws):
-        t[f"pipe.draw{i}"] = d
-    for i, l in enumerate(step_lat):
-        t[f"pipe.latents{i}"] = l
-    t["pipe.image"] = images
     pos = enc(inp["clip_pixels"], output_hidden_states=True).hidden_states[-2]
     neg = enc(torch.zeros_like(inp["clip_pixels"]), output_hidden_states=True).hidden_states[-2]
     t["pipe.ip_hidden_states"] = torch.cat([neg, pos])
+    for k, v in inp.items():
+        t[f"pipe.in.{k}"] = v
+
+    def run_ref(prefix, steps, strength, guidance, n_draws):
+        tu.RECORD = []
+        torch.manual_seed(4242)                           # the pose posterior is drawn from the GLOBAL generator (:1646)
+        step_lat = []
+        pipe.scheduler = SchedAdapter()
+        orig_step = pipe.scheduler.step
+
+        def rec_step(*a, **k):
+            out = orig_step(*a, **k)
+            step_lat.append(out[0].clone())
+            return out
+        pipe.scheduler.step = rec_step
+        images = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                      pooled_prompt_embeds=inp["pooled_prompt_embeds"], negative_pooled_prompt_embeds=inp["negative_pooled_prompt_embeds"],
+                      num_inference_steps=steps, generator=torch.Generator().manual_seed(7), strength=strength, pose_img=inp["pose_img"],
+                      text_embeds_cloth=inp["text_embeds_cloth"], cloth=inp["cloth"], mask_image=inp["mask_image"], image=inp["image"],
+                      height=H, width=W, guidance_scale=guidance, ip_adapter_image=inp["clip_pixels"], output_type="pt")[0]
+        draws, tu.RECORD = tu.RECORD, None
+        assert len(draws) in n_draws, (prefix, len(draws))
+        for i, d in enumerate(draws):
+            t[f"{prefix}.draw{i}"] = d
+        for i, l in enumerate(step_lat):
+            t[f"{prefix}.latents{i}"] = l
+        t[f"{prefix}.image"] = images
+
+    # the path inference.py takes: strength 1.0 (pure-noise start, every step), CFG on: 4 draws + one per DDPM step with t > 0
+    run_ref("pipe", steps, 1.0, 2.0, (4 + steps - 1, 4 + steps))
+    # the two other branches of __call__ in one run: strength 0.6 of 5 steps (-> the last 3 timesteps, start = add_noise(encode(image)):
+    # one more draw, FIRST) and guidance_scale 1.0 (no classifier-free guidance: conditional rows only)
+    run_ref("pipe2", 5, 0.6, 1.0, (5 + 3 - 1, 5 + 3))
 
 
 @torch.no_grad()

@@ -57,6 +57,12 @@ class Scheduler:
             sigma = 0.0
         return c_eps, c_x, sigma
 
+    def add_noise(self, x0, noise, t):
+        """diffusers SchedulerMixin.add_noise: sqrt(ab_t) x0 + sqrt(1 - ab_t) noise (used when strength < 1,
+        src/tryon_pipeline.py:889-893)."""
+        ab = float(self.alphas_cumprod[int(t)])
+        return ab ** 0.5 * x0 + (1.0 - ab) ** 0.5 * noise
+
     def step(self, eps, t, x, noise=None):
         c_eps, c_x, sigma = self.coeffs(t)
         out = c_x * x + c_eps * eps

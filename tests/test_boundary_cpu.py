@@ -157,8 +157,8 @@ def test_pipeline_argument_errors_and_no_cpu_path(tmp_path):
         pipe(**{**kw, "negative_prompt_embeds": z(B, 70, 128)})
     with pytest.raises(ValueError, match="cannot be undefined"):
         pipe(**{**kw, "image": None})
-    with pytest.raises(NotImplementedError, match="guidance_scale"):
-        pipe(**{**kw, "guidance_scale": 1.0})
+    with pytest.raises(ValueError, match="number of pipeline"):      # reference :1568-1572: int(2 * 0.3) = 0 steps left
+        pipe(**{**kw, "strength": 0.3})
     # the product has no CPU path: modules on the CPU refuse to run instead of falling back
     with pytest.raises(RuntimeError, match="GPU only"):
         pipe(**kw)

@@ -162,6 +162,21 @@ def test_pipeline_boundary_end_to_end():
               text_embeds_cloth=inp["text_embeds_cloth"], noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=n_steps),
               num_inference_steps=steps, guidance_scale=2.0, ip_hidden_states=torch.cat([neg, pos]), scheduler="ddpm")
     assert torch.equal(img_pt, ref)
+    # the other two branches of __call__: strength < 1 (draw order: init-image posterior FIRST, then the latent noise; 5 steps * 0.6
+    # -> the last 3) and guidance_scale <= 1 (no CFG: negative embeddings unused, conditional IP rows only)
+    torch.manual_seed(123)
+    img2 = pipe(generator=torch.Generator(DEV).manual_seed(7), output_type="pt", **{**call, "strength": 0.6, "guidance_scale": 1.0, "num_inference_steps": 5})[0]
+    gen = torch.Generator(DEV).manual_seed(7)
+    torch.manual_seed(123)
+    n_img, n_lat = draw(gen, torch.float32), draw(gen, DT)
+    n_masked, n_pose, n_cloth = draw(gen, torch.float32), draw(None, torch.float32), draw(gen, torch.float32)
+    n_steps = torch.stack([draw(gen, DT) for _ in range(3)])
+    ref2 = eng(image=inp["image"], mask_image=inp["mask_image"], pose_img=inp["pose_img"], cloth=inp["cloth"],
+               prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=None, pooled_prompt_embeds=inp["pooled_prompt_embeds"],
+               negative_pooled_prompt_embeds=None, text_embeds_cloth=inp["text_embeds_cloth"],
+               noise=dict(image=n_img, latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=n_steps),
+               num_inference_steps=5, strength=0.6, guidance_scale=1.0, ip_hidden_states=pos, scheduler="ddpm", image_dtype=DT)
+    assert torch.equal(img2, ref2) and not torch.equal(img2, img_pt)
     pil0 = torch.from_numpy(__import__("numpy").asarray(images[0][0])).float() / 255.0
     assert (pil0 - img_pt[0].permute(1, 2, 0).cpu()).abs().max() <= 0.5 / 255 + 1e-6
     # unet forward surface: tuple / .sample returns, garment feature list (src/unet_hacked_garmnet.py:1281-1284)

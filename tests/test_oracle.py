@@ -312,6 +312,19 @@ def _check_pipeline_against_reference_fixture(t):
     for i in range(n_steps):
         assert _rel(tr["step_latents"][i], t[f"pipe.latents{i}"]) <= PIN_TOL, (i, _rel(tr["step_latents"][i], t[f"pipe.latents{i}"]))
     assert _rel(img, t["pipe.image"]) <= PIN_TOL, _rel(img, t["pipe.image"])
+    # second reference run: strength 0.6 of 5 steps (the last 3 timesteps; the init-image posterior is the FIRST draw, then the
+    # latent noise: prepare_latents :883-889) and guidance_scale 1.0 (no classifier-free guidance; conditional IP rows only)
+    d2 = [t[f"pipe2.draw{i}"] for i in range(sum(k.startswith("pipe2.draw") for k in t))]
+    n2 = sum(k.startswith("pipe2.latents") for k in t)
+    assert n2 == 3 and len(d2) == 5 + n2
+    B = inp["image"].shape[0]
+    tr2 = {}
+    img2 = opipe.run(o_t, o_g, o_v, Scheduler("ddpm"), num_inference_steps=5, strength=0.6, guidance_scale=1.0, trace=tr2,
+                     ip_hidden_states=t["pipe.ip_hidden_states"][B:],
+                     noise=dict(image=d2[0], latents=d2[1], masked=d2[2], pose=d2[3], cloth=d2[4], steps=torch.stack(d2[5:])), **inp)
+    for i in range(n2):
+        assert _rel(tr2["step_latents"][i], t[f"pipe2.latents{i}"]) <= PIN_TOL, (i, _rel(tr2["step_latents"][i], t[f"pipe2.latents{i}"]))
+    assert _rel(img2, t["pipe2.image"]) <= PIN_TOL, _rel(img2, t["pipe2.image"])
 
 
 def test_oracle_pipeline_matches_reference_code_golden():

@@ -96,3 +96,41 @@ def test_mid_pipeline_parity(dtype):
     for k in ("resampler", "vae_encode", "vae_decode", "garment_feat_max", "tryon_eps", "tryon_eps_materialised_zeros"):
         assert r[k] <= t["stage"], (k, r)
     assert r["latents_final"] <= t["latents"] and r["image"] <= t["image"], r
+
+
+@pytest.mark.parametrize("case", ["strength0.6", "guidance1.0", "guidance0.5_strength0.8"])
+def test_strength_and_no_cfg_branches_match_oracle(case):
+    """The two `__call__` branches the try-on scripts do not take: strength < 1 (tryon_pipeline.py:987-995 timesteps subset,
+    :883-893 start from add_noise(encode(image))) and guidance_scale <= 1 (:440-442 no classifier-free guidance: the oracle runs
+    the conditional branch alone, the engine its batched step with guidance 1)."""
+    from idm_vton_amd.pipeline import TryonEngine
+    from oracle import pipeline as opipe
+    from oracle.scheduler import Scheduler
+    from tests import parity_utils as pu
+    strength = 0.6 if case == "strength0.6" else (0.8 if "strength0.8" in case else 1.0)
+    g = 1.0 if case == "guidance1.0" else (0.5 if "guidance0.5" in case else 2.0)
+    dt, B, steps = torch.float16, 1, 5
+    m = pu.build("tiny", dt, "cuda")
+    o_t, o_g, o_v = m["oracle"]
+    p_t, p_g, p_v, p_r = m["product"]
+    inp = pu.make_inputs(B, 128, 128, m["xd"], m["pooled"], m["enc_dim"], steps, dt)
+    inp["noise"]["image"] = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(77))
+    n_exec = min(int(steps * strength), steps)
+    inp["noise"]["steps"] = inp["noise"]["steps"][:n_exec]
+    o_inp = dict(inp)
+    p_inp = dict(inp)
+    if g <= 1:                                            # the reference hands the pipeline the conditional rows only
+        o_inp["ip_hidden_states"] = inp["ip_hidden_states"][B:]
+        p_inp["ip_hidden_states"] = inp["ip_hidden_states"][B:]
+        p_inp["negative_prompt_embeds"] = p_inp["negative_pooled_prompt_embeds"] = None
+    tr = {}
+    lat_o = opipe.run(o_t, o_g, o_v, Scheduler("ddpm"), num_inference_steps=steps, guidance_scale=g, strength=strength,
+                      return_latents=True, trace=tr, **o_inp)
+    assert len(tr["step_latents"]) == n_exec
+    eng = TryonEngine(p_t, p_g, p_v, p_r, dt, "cuda")
+    for kw in (dict(), dict(use_graph=True, overlap=True)):
+        st = eng.prepare(num_inference_steps=steps, guidance_scale=g, scheduler="ddpm", strength=strength, **p_inp)
+        assert len(st["timesteps"]) == n_exec
+        assert pu.relerr(st["latents"], tr["latents0"]) < 2e-3, "start latents (add_noise of the encoded image)"
+        lat_p = eng.denoise(st, **kw)
+        assert pu.relerr(lat_p, lat_o) <= TOL[dt]["latents"], (case, kw, pu.relerr(lat_p, lat_o))
