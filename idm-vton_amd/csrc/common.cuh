@@ -70,12 +70,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // Exchange between the two 32-lane halves of a wave without the LDS crossbar (v_permlane32_swap: lanes 32-63 of the first
 // operand swap with lanes 0-31 of the second): max / sum of a value with its partner lane (lane ^ 32).
 __device__ __forceinline__ float xhalf_max(float v) {

@@ -98,7 +98,7 @@ def hint(v, bn, bm):
 
 def gemm_probe():
     """Per shape: tile variants x {cold (L2/MALL flushed: the weights come from HBM as in the real loop), warm (same operands
-    re-used)}, the K-rotated walk (variant 3), and an activation pitch padded by 64 elements (L2 channel spread)."""
+    re-used)} and the same launch with the weights touched into cache first (idmvton_prefetch)."""
     res = {}
     flush = torch.empty(640 << 20, dtype=torch.uint8, device=DEV)
     cases = []
