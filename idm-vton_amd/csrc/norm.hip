@@ -108,7 +108,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_a
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
         if (psub < tpp) {
-            for (int pix = p0 + psub; pix < p1; pix += tpp) {
+            // four pixels' loads in flight per thread (the loop is latency bound: one dependent 16-byte load per iteration
+            // otherwise); accumulation order per thread is unchanged, so results are bit-identical to the rolled loop
+            int pix = p0 + psub;
+            for (; pix + 3 * tpp < p1; pix += 4 * tpp) {
+                v8 t[4];
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) t[u4] = *(const v8*)(src + ((size_t)b * a.HW + pix + u4 * tpp) * pitch + coff);
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = (float)t[u4][j]; s[j] += f; q[j] += f * f; }
+            }
+            for (; pix < p1; pix += tpp) {
                 const v8 t = *(const v8*)(src + ((size_t)b * a.HW + pix) * pitch + coff);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)t[j]; s[j] += f; q[j] += f * f; }
@@ -140,7 +152,15 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(double* stats, int bg, 
     const int i = blockIdx.x, lane = threadIdx.x;
     const double* part = stats + (size_t)2 * bg + (size_t)i * nblk * 2;
     double ds = 0.0, dq = 0.0;
-    for (int k = lane; k < nblk; k += 64) { ds += part[2 * k]; dq += part[2 * k + 1]; }
+    int k = lane;
+    for (; k + 3 * 64 < nblk; k += 4 * 64) {              // four independent loads in flight; same summation order
+        double ps[4], pq[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) { ps[u4] = part[2 * (k + 64 * u4)]; pq[u4] = part[2 * (k + 64 * u4) + 1]; }
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) { ds += ps[u4]; dq += pq[u4]; }
+    }
+    for (; k < nblk; k += 64) { ds += part[2 * k]; dq += part[2 * k + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     if (lane == 0) { stats[2 * i] = ds; stats[2 * i + 1] = dq; }
@@ -177,7 +197,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_a
         }
         if (psub < tpp) {
             T* dst = (T*)a.y;
-            for (int pix = p0 + psub; pix < p1; pix += tpp) {
+            int pix = p0 + psub;
+            for (; pix + 3 * tpp < p1; pix += 4 * tpp) {          // four pixels' loads in flight per thread
+                v8 t[4];
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) t[u4] = *(const v8*)(src + ((size_t)b * a.HW + pix + u4 * tpp) * pitch + coff);
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) {
+                    v8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float f = (float)t[u4][j] * sc[j] + sh[j];
+                        if (a.silu) f = silu_f(f);
+                        o[j] = (T)f;
+                    }
+                    *(v8*)(dst + ((size_t)b * a.HW + pix + u4 * tpp) * a.C + c0) = o;
+                }
+            }
+            for (; pix < p1; pix += tpp) {
                 const size_t row = (size_t)b * a.HW + pix;
                 const v8 t = *(const v8*)(src + row * pitch + coff);
                 v8 o;

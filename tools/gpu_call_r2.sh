@@ -2,9 +2,9 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fullsize_gpu.py tests/test_dropin_gpu.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -8
-for mode in "" "--no-graph" "--no-overlap"; do
-  tag=$(echo "default$mode" | tr -d ' ')
-  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline $mode > $O/r2r_bench_$tag.json 2> $O/r2r_bench_$tag.err; echo "$tag rc=$? $(python -c "
-import json; d=json.loads(open('$O/r2r_bench_$tag.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")"
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "groupnorm or layernorm or elementwise" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "tiny_pipeline or bit_reproducible" 2>&1 | tail -3
+for tag in cur prev cur prev; do
+  lib=$R/idm-vton_amd/libidmvton_hip.so; [ $tag != cur ] && lib=$R/idm-vton_amd/libidmvton_hip_$tag.so
+  IDMVTON_HIP_LIB=$lib timeout 100 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', round(d['value'],4), round(d['ms_per_step'],1), d['roofline']['step_kernel_ms'])"
 done
