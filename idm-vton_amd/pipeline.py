@@ -120,8 +120,8 @@ class TryonEngine:
 
     # -------------------------------------------------------------------------------------------- one step
     def _step(self, st, temb_t, temb_g, coef, noise):
-        """Serial form of one loop iteration (tryon_pipeline.py:1765-1866) on the current stream: parity tests, traces and
-        the per-kernel roofline leg of bench.py use this; the throughput path is the two-stream form below."""
+        """One loop iteration in the reference's own order (tryon_pipeline.py:1765-1866: GarmentNet for THIS timestep, then
+        TryonNet) on the current stream.  Debugging aid (tools/gpu_debug.py); the loop itself runs in blocks, below."""
         B, h, w = st["B"], st["h"], st["w"]
         ops.pack_input(st["latents"], st["cond"], st["x_in"])                              # :1769,1777
         _, feats = self.unet_encoder.forward(st["cloth"], temb_g, st["ctx_g"], B, h, w)    # :1787
