@@ -677,9 +677,9 @@ extern "C" int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream) {
                   IDMVTON_E_SHAPE, "attn_fwd: seg %d nk=%d b0=%d", ss, a->nk[ss], a->seg_b0[ss]);
         const int krows = a->k_rows[ss] > 0 ? a->k_rows[ss] : a->nk[ss];
         CHECK_ARG(krows >= a->nk[ss], IDMVTON_E_SHAPE, "attn_fwd: seg %d k_rows=%d < nk", ss, krows);
-        CHECK_ARG(a->ldk[ss] % 8 == 0 && a->ldvt[ss] % 8 == 0 && a->ldvt[ss] >= ((a->nk[ss] + 7) & ~7) && a->ldk[ss] >= a->heads * 64 &&
+        CHECK_ARG(a->ldk[ss] % 8 == 0 && a->ldvt[ss] % 16 == 0 && a->ldvt[ss] >= ((a->nk[ss] + 15) & ~15) && a->ldk[ss] >= a->heads * 64 &&
                   ((uintptr_t)a->k[ss] & 15) == 0 && ((uintptr_t)a->vt[ss] & 15) == 0, IDMVTON_E_ALIGN,
-                  "attn_fwd: seg %d ldk=%d ldvt=%d", ss, a->ldk[ss], a->ldvt[ss]);
+                  "attn_fwd: seg %d ldk=%d ldvt=%d (V^T is read in key order: ldvt %% 16 == 0, ldvt >= roundup16(nk))", ss, a->ldk[ss], a->ldvt[ss]);
         const int nb = a->B - a->seg_b0[ss];
         const uint64_t kb = (uint64_t)nb * krows * a->ldk[ss] * 2, vb = (uint64_t)nb * a->heads * 64 * a->ldvt[ss] * 2;
         CHECK_ARG(kb < 0x80000000ull && vb < 0x80000000ull, IDMVTON_E_SHAPE, "attn_fwd: seg %d K/V^T >= 2 GiB", ss);

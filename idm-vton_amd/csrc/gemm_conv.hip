@@ -36,6 +36,7 @@ struct GemmParams {
     int colscale_n; float colscale;
     int tiles_m, tiles_n;
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
+    int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -178,14 +179,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
                     }
                     if (res) {
-                        const v8 rr = *(const v8*)(res + (size_t)m * p.ldr + n);
+                        if (p.res32) {                     // block-uniform: the fp32 residual stream
+                            const float4* rp = (const float4*)((const float*)p.res + (size_t)m * p.ldr + n);
+                            const float4 r0 = rp[0], r1 = rp[1];
+                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        } else {
+                            const v8 rr = *(const v8*)(res + (size_t)m * p.ldr + n);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+                            for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+                        }
                     }
-                    v8 o;
+                    if (p.out32) {
+                        float4* op = (float4*)((float*)p.out + (size_t)m * p.ldo + n);
+                        op[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        op[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        v8 o;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
-                    *(v8*)(out + (size_t)m * p.ldo + n) = o;
+                        for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
+                        *(v8*)(out + (size_t)m * p.ldo + n) = o;
+                    }
                 }
         }
         return;
@@ -607,6 +621,13 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     int variant = 1, bn = 64, bm = 64;
     static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
     if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
+    p.res32 = (a->io_flags & IDMVTON_IO_RES_F32) ? 1 : 0;
+    p.out32 = (a->io_flags & IDMVTON_IO_OUT_F32) ? 1 : 0;
+    if (p.res32 || p.out32) {
+        CHECK_ARG((a->io_flags & ~3) == 0 && !geglu && !a->vt, IDMVTON_E_ARG, "gemm_conv: io_flags=%d (fp32 res / out: no GEGLU, no vt)", a->io_flags);
+        CHECK_ARG(!p.res32 || a->res, IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_RES_F32 without res");
+        CHECK_ARG(p.wide, IDMVTON_E_ALIGN, "gemm_conv: the fp32 residual stream needs the 16-byte epilogue (N, ldo, ldr multiples of 8, 16-byte aligned pointers)");
+    }
     if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0x7fff; }
     else {
         // No hint: the largest ring tile that still gives every CU a tile (measured rule, profiles/r01_tune_report_*.json:

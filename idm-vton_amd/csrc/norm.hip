@@ -6,7 +6,7 @@
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per row; lane l owns 8-element chunks l, l+64, l+128, l+192 (C <= 2048).  16-byte loads, fp32 math.
-template <typename T, int NCH>
+template <typename T, int NCH, bool X32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_args a) {
     typedef typename VT<T>::v8 v8;
     const int lane = threadIdx.x & 63;
@@ -14,15 +14,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_
     if (row >= a.rows) return;
     const int nchunk = a.C >> 3;
     const T* x = (const T*)a.x + (size_t)row * a.ldx;
+    const float* xf = (const float*)a.x + (size_t)row * a.ldx;      // X32: the fp32 residual stream
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const v8 t = *(const v8*)(x + c * 8);
+            if constexpr (X32) {
+                const float4 t0 = *(const float4*)(xf + c * 8), t1 = *(const float4*)(xf + c * 8 + 4);
+                v[i][0] = t0.x; v[i][1] = t0.y; v[i][2] = t0.z; v[i][3] = t0.w;
+                v[i][4] = t1.x; v[i][5] = t1.y; v[i][6] = t1.z; v[i][7] = t1.w;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+                for (int j = 0; j < 8; ++j) s += v[i][j];
+            } else {
+                const v8 t = *(const v8*)(x + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
@@ -62,10 +71,15 @@ template <typename T>
 static int launch_ln(const idmvton_layernorm_args& a, hipStream_t st) {
     const dim3 grid((a.rows + 3) / 4), block(256);
     const int nch = ((a.C >> 3) + 63) / 64;
-    if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, a);
-    else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, a);
-    else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, st, a);
+    if (a.x_f32) {
+        if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1, true>), grid, block, 0, st, a);
+        else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2, true>), grid, block, 0, st, a);
+        else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((layernorm_kernel<T, 4, true>), grid, block, 0, st, a);
+    } else if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1, false>), grid, block, 0, st, a);
+    else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2, false>), grid, block, 0, st, a);
+    else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<T, 4, false>), grid, block, 0, st, a);
     CHECK_LAUNCH("layernorm");
     return IDMVTON_OK;
 }

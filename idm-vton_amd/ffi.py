@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_
 F16, BF16, F32 = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS = 0, 1
+IO_RES_F32, IO_OUT_F32 = 1, 2
 MAX_SEG = 12
 
 i32, u32, f32, vp = C.c_int32, C.c_uint32, C.c_float, C.c_void_p
@@ -26,7 +27,7 @@ class GemmConvArgs(C.Structure):
                 ("M", i32), ("Ho", i32), ("Wo", i32), ("Hi", i32), ("Wi", i32), ("stride", i32), ("ups", i32),
                 ("out", vp), ("ldo", i32), ("bias", vp), ("rowbias", vp), ("rowbias_ld", i32),
                 ("rows_per_group", i32), ("res", vp), ("ldr", i32), ("mode", i32), ("vt", vp), ("vt_n0", i32),
-                ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("colscale_n", i32), ("colscale", f32)]
+                ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("io_flags", i32), ("colscale_n", i32), ("colscale", f32)]
 
 
 class AttnArgs(C.Structure):
@@ -37,7 +38,7 @@ class AttnArgs(C.Structure):
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("dtype", i32), ("rows", i32), ("C", i32), ("x", vp), ("ldx", i32), ("gamma", vp), ("beta", vp),
-                ("eps", f32), ("y", vp), ("ldy", i32), ("y2", vp), ("ldy2", i32)]
+                ("eps", f32), ("y", vp), ("ldy", i32), ("y2", vp), ("ldy2", i32), ("x_f32", i32)]
 
 
 class GroupNormArgs(C.Structure):

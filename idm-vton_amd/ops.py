@@ -88,8 +88,9 @@ class SegSpec:
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, quick_gelu=False, vt=None,
-              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0):
+              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
+    fp32 residual stream: a float32 `res` is read as fp32; out_f32=True (or a float32 `out`) writes fp32 (io_flags).
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
     kernel's key order (see key_order()), False as a plain transpose."""
     a = ffi.GemmConvArgs()
@@ -109,7 +110,9 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.M, a.Ho, a.Wo, a.Hi, a.Wi, a.stride, a.ups = M, Ho, Wo, Hi, Wi, stride, int(bool(ups))
     n_out = N // 2 if geglu else (vt_n0 if vt is not None else N)
     if out is None and n_out > 0:
-        out = torch.empty((M, n_out), dtype=w.dtype, device=w.device)
+        out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else w.dtype, device=w.device)
+    a.io_flags = (ffi.IO_RES_F32 if res is not None and res.dtype == torch.float32 else 0) | \
+                 (ffi.IO_OUT_F32 if out is not None and out.dtype == torch.float32 else 0)
     a.out = _ptr(out)
     a.ldo = (ldo if ldo is not None else (out.stride(-2) if out is not None else 0))
     a.bias = _ptr(bias)
@@ -129,7 +132,7 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
             seen.add(sg.t.data_ptr())
             xbytes += sg.t.numel() * sg.t.element_size()
     esz = w.element_size()
-    obytes = (M * (N // 2 if geglu else N)) * esz + (M * N * esz if res is not None else 0)
+    obytes = (M * (N // 2 if geglu else N)) * (out.element_size() if out is not None else esz) + (M * N * res.element_size() if res is not None else 0)
     _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
 
@@ -211,17 +214,18 @@ def attention_small(q, k, v, out, heads, d, *, scale, causal=False, B=None, Lq=N
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None, out2=None):
-    """x: [rows][C] (row stride x.stride(0))."""
+    """x: [rows][C] (row stride x.stride(0)); float32 x = the fp32 residual stream (output in gamma's dtype)."""
     rows, Cc = x.shape
     if out is None:
-        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+        out = torch.empty((rows, Cc), dtype=gamma.dtype, device=x.device)
     a = ffi.LayerNormArgs()
-    a.dtype, a.rows, a.C = _dt(x), rows, Cc
+    a.dtype, a.rows, a.C = _dt(gamma), rows, Cc
+    a.x_f32 = int(x.dtype == torch.float32)
     a.x, a.ldx = _ptr(x), x.stride(0)
     a.gamma, a.beta, a.eps = _ptr(gamma), _ptr(beta), eps
     a.y, a.ldy = _ptr(out), out.stride(0)
     a.y2, a.ldy2 = _ptr(out2), (out2.stride(0) if out2 is not None else 0)
-    _call("idmvton_layernorm", a, bytes_=(2.0 + (out2 is not None)) * rows * Cc * x.element_size())
+    _call("idmvton_layernorm", a, bytes_=(x.element_size() + (1.0 + (out2 is not None)) * out.element_size()) * rows * Cc)
     return out
 
 

@@ -47,8 +47,12 @@ class _Conv:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=True):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        # fp32 residual stream: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
+        # attentionhacked_tryon.py:348,384,412) stays fp32 from proj_in to the last block's ff.net.2, whose output is rounded once
+        # for proj_out (its GEMM operand).  The reference's fp16 autocast rounds it after every add; see DESIGN.md section 5.
+        self.stream_f32 = bool(stream_f32)
         self.topo = unet_topology(cfg)
         sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items() if not k.startswith("encoder_hid_proj.")}
         self.sd = sd
@@ -207,7 +211,7 @@ class HipUNet:
             out, _, _ = self._conv3(g2, r["conv2"], B, H, W, res=xa.reshape(B * H * W, -1))
         return out
 
-    def _block(self, blk, hs, B, N, C, ctx, garment, feats_out, stop=None):
+    def _block(self, blk, hs, B, N, C, ctx, garment, feats_out, stop=None, last=False):
         """BasicTransformerBlock: tryon src/attentionhacked_tryon.py:284-415, garmnet src/attentionhacked_garmnet.py:284-406."""
         sd, p, heads = self.sd, blk["p"], blk["heads"]
         dt, dev = self.dtype, self.device
@@ -240,7 +244,8 @@ class HipUNet:
             segs.append(dict(k=kg, vt=vtg, nk=N, ldk=C, ldvt=N, b0=B - Bg))
         att = torch.empty(M, C, dtype=dt, device=dev)
         ops.attention(qk, att, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C, q_prescaled=True)
-        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs)
+        f32 = hs.dtype == torch.float32                          # the fp32 residual stream (see __init__)
+        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32)
         # cross attention
         n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
         q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
@@ -252,11 +257,11 @@ class HipUNet:
             ops.attention(q2, att2, [seg_t, seg_i], heads, mode=ffi.ATTN_CROSS, ip_scale=self.ip_scale, B=B, Nq=N, ldq=C, ldo=C)
         else:
             ops.attention(q2, att2, [seg_t], heads, B=B, Nq=N, ldq=C, ldo=C)
-        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs)
+        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32)
         # feed-forward (GEGLU fused into the first GEMM's epilogue)
         n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
         gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
-        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs)
+        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs, out_f32=f32 and not last)
         return hs
 
     def _transformer(self, p, x, B, H, W, ctx, garment, feats_out, stop_after_feats=None):
@@ -264,9 +269,9 @@ class HipUNet:
         sd, tf = self.sd, self.tf[p]
         C, N = tf["ch"], H * W
         g = self._gn(x, None, p + ".norm", 1e-6, False)
-        hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"])
+        hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32)
         for blk in tf["blocks"]:
-            hs = self._block(blk, hs, B, N, C, ctx, garment, feats_out, stop_after_feats)
+            hs = self._block(blk, hs, B, N, C, ctx, garment, feats_out, stop_after_feats, last=blk is tf["blocks"][-1])
             if hs is None:
                 return None
         out = ops.linear(hs, sd[p + ".proj_out.weight"], bias=sd[p + ".proj_out.bias"], res=x.reshape(B * N, C))

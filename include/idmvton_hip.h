@@ -63,8 +63,9 @@ typedef struct {
 
 enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1, IDMVTON_EPI_GELU = 2 /* gelu_erf(acc+bias+rowbias) then +res */,
        IDMVTON_EPI_QUICKGELU = 3 /* x*sigmoid(1.702x): CLIP-L text MLP (transformers hidden_act "quick_gelu") */ };
+enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2 };
 typedef struct {
-    int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type) */
+    int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type; see io_flags) */
     const void* w; int32_t N; int32_t Ktot;
     int32_t nseg; idmvton_seg seg[IDMVTON_MAX_SEG];
     int32_t M, Ho, Wo, Hi, Wi, stride, ups;
@@ -84,6 +85,11 @@ typedef struct {
                                     the token index are swapped (position p holds token (p&~12)|((p&4)<<1)|((p&8)>>1)), which makes
                                     the 8 keys one half-wave contracts per PV MFMA one aligned 16-byte read.  Needs vt_tokens % 16 == 0.
                                     0: plain transpose (the VAE mid block uses V^T as a GEMM weight). */
+    int32_t io_flags;            /* IDMVTON_IO_RES_F32: `res` holds fp32 (ldr in fp32 elements); IDMVTON_IO_OUT_F32: `out` is written as fp32 (ldo in
+                                    fp32 elements).  The fp32 RESIDUAL STREAM of a Transformer2DModel: the block-to-block hidden state
+                                    (src/attentionhacked_tryon.py:348,384,412: three `+ hidden_states` per block, 210 per TryonNet forward) is
+                                    kept in fp32 between the to_out / ff.net.2 epilogues and the next LayerNorm instead of being rounded to
+                                    16 bits after every add; both need the 16-byte epilogue (all strides / N multiples of 8).  0 = off. */
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */
@@ -158,6 +164,7 @@ typedef struct {
     const void* gamma; const void* beta; float eps;
     void* y; int32_t ldy;
     void* y2; int32_t ldy2;
+    int32_t x_f32;               /* 1: x is fp32 (ldx in fp32 elements): the fp32 residual stream written by gemm_conv's IDMVTON_IO_OUT_F32 */
 } idmvton_layernorm_args;
 int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream);
 
