@@ -291,7 +291,7 @@ class UNet2DConditionModel(nn.Module):
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep], dtype=torch.int64)
         if t.ndim == 0:
             t = t[None]
-        t = t.expand(sample.shape[0])                                                   # :1132
+        t = t.to(sample.device).expand(sample.shape[0])                                 # :1132 (tests may run this module on the GPU)
         emb = self.time_embedding(self.time_proj(t).to(sample.dtype))                   # :1134-1141
         if self.cfg.addition_embed_type == "text_time":                                 # :1174-1190
             text_embeds = added_cond_kwargs["text_embeds"]

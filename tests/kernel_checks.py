@@ -333,6 +333,34 @@ def check_layernorm(rows, Cc, dtype, dev, seed=0):
     return max(relerr(out, ref), relerr(o2, ref))
 
 
+def check_stream_f32(M, N, K, dtype, dev, tile_hint=0, seed=0):
+    """The fp32 residual stream (gemm_conv io_flags, layernorm x_f32): fp32 res in / fp32 out, fp32 res in / 16-bit out, 16-bit
+    res in / fp32 out, each against the fp32 reference with an fp32-ONLY tolerance where the output is fp32 (the only roundings left
+    are the 16-bit operands, which the reference shares), then LayerNorm of the fp32 result."""
+    from idm_vton_amd import ops
+    x = _r(M, K, dtype=dtype, dev=dev, seed=seed)
+    w = _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 1)
+    b = _r(N, dtype=dtype, dev=dev, seed=seed + 2)
+    r32 = _r(M, N, dtype=torch.float32, dev=dev, scale=3.0, seed=seed + 3)               # NOT representable in 16 bits
+    ref = x.float() @ w.float().t() + b.float() + r32
+    o32 = ops.linear(x, w, bias=b, res=r32, out_f32=True, tile_hint=tile_hint)
+    assert o32.dtype == torch.float32
+    e = relerr(o32, ref) / 2e-5 * TOL[dtype]                                              # fp32 in, fp32 out: <= 2e-5, scaled to the caller's tolerance
+    o16 = ops.linear(x, w, bias=b, res=r32, tile_hint=tile_hint)
+    assert o16.dtype == dtype
+    e = max(e, relerr(o16, ref))
+    r16 = r32.to(dtype)
+    o32b = ops.linear(x, w, bias=b, res=r16, out_f32=True, tile_hint=tile_hint)
+    e = max(e, relerr(o32b, x.float() @ w.float().t() + b.float() + r16.float()) / 2e-5 * TOL[dtype])
+    g = _r(N, dtype=dtype, dev=dev, seed=seed + 4)
+    bt = _r(N, dtype=dtype, dev=dev, seed=seed + 5)
+    if N <= 2048:
+        y = ops.layernorm(o32, g, bt, 1e-5)
+        assert y.dtype == dtype
+        e = max(e, relerr(y, F.layer_norm(o32, (N,), g.float(), bt.float(), 1e-5)))
+    return e
+
+
 def check_groupnorm(B, HW, Cc, dtype, dev, groups=32, silu=True, split=0, eps=1e-5, seed=0):
     from idm_vton_amd import ops
     x = _r(B, HW, Cc, dtype=dtype, dev=dev, scale=2.0, seed=seed) + 0.7
@@ -502,6 +530,10 @@ def all_checks(dev="cuda"):
         add("attn_self_N16", lambda dt=dt: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1))
         add("attn_cross_77_16_N768", lambda dt=dt: check_attn_cross(4, 4, 768, dt, dev))
         add("attn_cross_scale0.5_N200", lambda dt=dt: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5))
+        for hint, tag in ((0, "auto"),) + tuple(RING_TILES):
+            add(f"stream_f32_768x640x640_{tag}", lambda dt=dt, hint=hint: check_stream_f32(768, 640, 640, dt, dev, tile_hint=hint))
+        add("stream_f32_ragged_1000x328x192", lambda dt=dt: check_stream_f32(1000, 328, 192, dt, dev))
+        add("stream_f32_3072x1280x5120", lambda dt=dt: check_stream_f32(3072, 1280, 5120, dt, dev))
         add("layernorm_640", lambda dt=dt: check_layernorm(1000, 640, dt, dev))
         add("layernorm_1280", lambda dt=dt: check_layernorm(3072, 1280, dt, dev))
         add("layernorm_64", lambda dt=dt: check_layernorm(37, 64, dt, dev))
