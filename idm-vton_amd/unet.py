@@ -47,11 +47,13 @@ class _Conv:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=True):
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
-        # fp32 residual stream: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
+        # stream_f32: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
         # attentionhacked_tryon.py:348,384,412) stays fp32 from proj_in to the last block's ff.net.2, whose output is rounded once
-        # for proj_out (its GEMM operand).  The reference's fp16 autocast rounds it after every add; see DESIGN.md section 5.
+        # for proj_out (its GEMM operand).  Off by default: the reference's fp16 autocast rounds the stream after every add, and
+        # measured at full size the option lowers the latent error by 10-35 % for 2.4 % of throughput --
+        # operand rounding inside the branches, not the stream, is what bf16 storage costs.
         self.stream_f32 = bool(stream_f32)
         self.topo = unet_topology(cfg)
         sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items() if not k.startswith("encoder_hid_proj.")}

@@ -11,6 +11,10 @@ What is executed from /root/reference, unmodified, imported by path with `tests/
   src/unet_block_hacked_*.py          CrossAttnDown/Up, Down/Up, Mid block forwards and skip handling
   src/unet_hacked_tryon.py            UNet2DConditionModel.__init__ + forward (:1006-1395), IP processors installed at :773-791
   src/unet_hacked_garmnet.py          UNet2DConditionModel.forward (:917-1284) -> ((sample,), garment_features)
+  src/unet_block_hacked_tryon.py      the VAE building blocks the reference carries: UNetMidBlock2D (:505-627, attention called on the
+                                      4-D map through the reference's own AttnProcessor2_0, ip_adapter/attention_processor.py:213-276:
+                                      group_norm / residual_connection / rescale branch), DownEncoderBlock2D (:1292-1349, padding-0
+                                      downsampler), UpDecoderBlock2D (:2511-2568)  -> pins the blocks of oracle/vae.py
 
 This script must NOT see the repository root on sys.path: the repo's own `src/` and `ip_adapter/` packages (the product's
 import-path mirrors) would shadow the reference's.  oracle/make_golden.py launches it as a subprocess with cwd=/tmp.
@@ -199,6 +203,42 @@ def pipeline_fixture(t, pc, ref_t, ref_g):
 
 
 @torch.no_grad()
+def vae_blocks_fixture(t):
+    """The reference-held VAE blocks, constructed the way diffusers' Encoder / Decoder construct them for the SDXL AutoencoderKL
+    (resnet_eps 1e-6, act silu, temb_channels None, groups G, single-head attention with head_dim = channels, encoder downsample
+    padding 0), on seeded weights and inputs.  Stored: every block's state dict, input and output."""
+    from src.unet_block_hacked_tryon import DownEncoderBlock2D, UNetMidBlock2D, UpDecoderBlock2D
+    from ip_adapter.attention_processor import AttnProcessor2_0 as RefAttnProc
+    G = 8
+    gen = torch.Generator().manual_seed(977)
+
+    def seed(mod, name):
+        for k, v in mod.state_dict().items():
+            base = 1.0 if (k.endswith("weight") and v.dim() == 1) else 0.0                 # GroupNorm gamma around 1
+            v.copy_(torch.randn(v.shape, generator=gen) * (0.08 if v.dim() > 1 else 0.3) + base)
+            t[f"vae.{name}.sd.{k}"] = v.clone()
+
+    mid = UNetMidBlock2D(in_channels=64, resnet_eps=1e-6, resnet_act_fn="silu", output_scale_factor=1, resnet_time_scale_shift="default",
+                         attention_head_dim=64, resnet_groups=G, temb_channels=None).eval()
+    assert mid.attentions[0].group_norm is not None and mid.attentions[0].residual_connection and mid.attentions[0].heads == 1
+    mid.attentions[0].set_processor(RefAttnProc())                                          # the reference's own processor
+    down = DownEncoderBlock2D(num_layers=2, in_channels=32, out_channels=64, add_downsample=True, resnet_eps=1e-6,
+                              downsample_padding=0, resnet_act_fn="silu", resnet_groups=G).eval()
+    down_last = DownEncoderBlock2D(num_layers=2, in_channels=64, out_channels=64, add_downsample=False, resnet_eps=1e-6,
+                                   downsample_padding=0, resnet_act_fn="silu", resnet_groups=G).eval()
+    up = UpDecoderBlock2D(num_layers=3, in_channels=64, out_channels=32, add_upsample=True, resnet_eps=1e-6, resnet_act_fn="silu",
+                          resnet_groups=G, temb_channels=None).eval()
+    up_last = UpDecoderBlock2D(num_layers=3, in_channels=32, out_channels=32, add_upsample=False, resnet_eps=1e-6, resnet_act_fn="silu",
+                               resnet_groups=G, temb_channels=None).eval()
+    r = lambda *s: torch.randn(*s, generator=gen)
+    for name, blk, x in (("mid", mid, r(2, 64, 9, 7)), ("down", down, r(2, 32, 13, 11)), ("down_last", down_last, r(2, 64, 6, 5)),
+                         ("up", up, r(2, 64, 6, 5)), ("up_last", up_last, r(2, 32, 12, 10))):
+        seed(blk, name)
+        t[f"vae.{name}.x"] = x
+        t[f"vae.{name}.y"] = blk(x)
+
+
+@torch.no_grad()
 def main(out_path):
     from src.unet_hacked_tryon import UNet2DConditionModel as RefTryon
     from src.unet_hacked_garmnet import UNet2DConditionModel as RefGarm
@@ -257,6 +297,7 @@ def main(out_path):
               "blk_g.feat": exported[0]})
 
     pipeline_fixture(t, pc, ref_t, ref_g)
+    vae_blocks_fixture(t)
 
     save_file({k: v.contiguous() for k, v in t.items()}, out_path,
               metadata={"generator": "oracle/make_golden_ref.py", "reference": REF, "n_garm_feats": str(len(feats)),

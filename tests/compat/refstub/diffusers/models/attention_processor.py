@@ -1,6 +1,9 @@
 """diffusers 0.25.0 `Attention` (the module the reference's BasicTransformerBlock builds, src/attentionhacked_tryon.py:201-240)
 and its default `AttnProcessor2_0` (GarmentNet keeps it: SURVEY.md 8a row a9).  Written from the published semantics of that
-release; only the configuration the SDXL UNets use is implemented (no group_norm / spatial_norm / added_kv / norm_cross)."""
+release; implemented: the configuration the SDXL UNets use, plus the VAE mid-block form the reference's own `UNetMidBlock2D`
+constructs (src/unet_block_hacked_tryon.py:585-597: `norm_num_groups` -> GroupNorm(query_dim, eps, affine), bias=True,
+residual_connection=True, rescale_output_factor, upcast_softmax, _from_deprecated_attn_block).  Not implemented: spatial_norm /
+added_kv / norm_cross."""
 from typing import Union
 
 import torch
@@ -77,9 +80,11 @@ class Attention(nn.Module):
         self.sliceable_head_dim = heads
         self.added_kv_proj_dim = added_kv_proj_dim
         self.only_cross_attention = only_cross_attention
-        if norm_num_groups is not None or spatial_norm_dim is not None or cross_attention_norm is not None or added_kv_proj_dim is not None:
-            raise NotImplementedError("not constructed on the IDM-VTON UNet path")
-        self.group_norm = None
+        if spatial_norm_dim is not None or cross_attention_norm is not None or added_kv_proj_dim is not None:
+            raise NotImplementedError("not constructed on the IDM-VTON UNet / VAE path")
+        # diffusers 0.25 Attention.__init__: GroupNorm over the query channels, applied by the processor on [b, c, tokens]
+        self.group_norm = (nn.GroupNorm(num_channels=query_dim, num_groups=norm_num_groups, eps=eps, affine=True)
+                           if norm_num_groups is not None else None)
         self.spatial_norm = None
         self.norm_cross = None
         linear_cls = nn.Linear if USE_PEFT_BACKEND else LoRACompatibleLinear

@@ -11,8 +11,9 @@ values (one seeded bf16-rounded set, exactly representable in fp16 and fp32) and
              rounded to fp16 for PV) the reference gets from F.scaled_dot_product_attention (ip_adapter/attention_processor.py:258).
              Its error against the fp32 oracle IS "the stated fp16 tolerance" the north star refers to; the fp16 HIP path must not
              exceed it (bars below are multiples of this leg, not of the implementation's own numbers).
-  hip_f16, hip_bf16          the product, storage fp16 / bf16, fp32 residual stream inside each Transformer2DModel (default)
-  hip_f16_s16, hip_bf16_s16  the product with the residual stream rounded to the storage dtype after every add (A/B)
+  hip_f16, hip_bf16          the product, storage fp16 / bf16 (default: the transformer residual stream is rounded to the storage dtype
+                             after every add, as the reference's autocast does)
+  hip_f16_s32, hip_bf16_s32  the product with the fp32 residual stream inside each Transformer2DModel (HipUNet(stream_f32=True): A/B)
 
 The fp32 oracle is EXECUTED ON THE GPU by torch (rocBLAS fp32 GEMMs, torch's own im2col convolution -- MIOpen is switched off so a
 fresh box does not spend minutes in kernel search) so that 30-step, batch-2 and 192x128-latent comparisons take seconds instead of
@@ -74,8 +75,8 @@ def ref_policy():
         layers.sdpa = keep
 
 
-LEGS = {"hip_bf16": (torch.bfloat16, True), "hip_f16": (torch.float16, True),
-        "hip_bf16_s16": (torch.bfloat16, False), "hip_f16_s16": (torch.float16, False)}
+LEGS = {"hip_bf16": (torch.bfloat16, False), "hip_f16": (torch.float16, False),
+        "hip_bf16_s32": (torch.bfloat16, True), "hip_f16_s32": (torch.float16, True)}
 
 
 class World:
@@ -88,7 +89,7 @@ class World:
         self.results, self.timing = {}, {}
         torch.backends.cudnn.enabled = False               # oracle convs: torch's own kernels, no MIOpen search / JIT (the product uses neither)
         t0 = time.time()
-        eng0, cfgs, state = bench.build_engine(torch.bfloat16, dev, 0, 30, return_state=True, stream_f32=True)
+        eng0, cfgs, state = bench.build_engine(torch.bfloat16, dev, 0, 30, return_state=True, stream_f32=False)
         self.eng = {}
         for name in legs:
             dt, s32 = LEGS[name]
@@ -301,7 +302,7 @@ def stage_vae(Wd, H, W, B=1):
     torch.cuda.synchronize()
     Wd.timing["oracle32_vae_s"] = time.time() - t0
     for leg, eng in Wd.eng.items():
-        if leg.endswith("_s16"):
+        if leg.endswith("_s32"):
             continue                                          # the VAE has no transformer stream: same kernels as the default legs
         d = eng.vae.decode(z)
         Wd.put("cfg2_vae_decode", leg, rel=rel(d, dec32), rms=rms(d, dec32))

@@ -8,8 +8,7 @@ tolerance"; the tolerance is MEASURED here as the `ref_fp16` leg -- the oracle r
 (fp16 weights + torch.autocast, inference.py:233-262,339) against the fp32 oracle:
 
   * fp16 product  <= FP16_FACTOR x ref_fp16   (the product must be at least as close to fp32 as the reference's own execution);
-  * bf16 product  <= BF16_FACTOR x ref_fp16   (bf16 storage has 3 fewer mantissa bits than fp16: unit roundoff x 8; the fp32
-                                               residual stream is what keeps the end-to-end factor below that);
+  * bf16 product  <= BF16_FACTOR x ref_fp16   (bf16 storage has 3 fewer mantissa bits than fp16: unit roundoff x 8);
   * the VAE stages have no reduced-precision reference policy (the reference upcasts its VAE to fp32) and keep absolute bars:
     one 16-bit rounding of each of ~60 chained feature maps.
 """
@@ -104,9 +103,8 @@ def test_config4_one_full_step(world):
 
 
 def test_residual_stream_ab_is_recorded(world):
-    """The 16-bit-stream legs are measurements (the A/B behind the fp32 residual stream), not a contract: present and finite."""
+    """The fp32-residual-stream legs (HipUNet(stream_f32=True)) are held to the same bars as the default legs."""
     for stage in ("cfg2_unets", "cfg2_b2_2steps"):
         _run(world, stage)
-    for key in ("cfg2_tryon_eps", "cfg2_b2_ddpm2_latents"):
-        for leg in ("hip_bf16_s16", "hip_f16_s16"):
-            assert world.results[key][leg]["rel"] < 1.0
+    for key in ("cfg2_garment_features", "cfg2_tryon_eps", "cfg2_b2_ddpm2_latents"):
+        _check(world, key, legs=("hip_bf16_s32", "hip_f16_s32"))

@@ -261,6 +261,29 @@ def _check_blocks_against_reference_fixture(t):
         assert _rel(ref_like, a2.to_out[0](man)) <= PIN_TOL
 
 
+def _check_vae_blocks_against_reference_fixture(t):
+    """oracle/vae.py's blocks == the VAE building blocks the reference carries (src/unet_block_hacked_tryon.py: UNetMidBlock2D
+    :505-627 with the reference's AttnProcessor2_0 on the 4-D map, DownEncoderBlock2D :1292-1349, UpDecoderBlock2D :2511-2568):
+    same state-dict keys (strict load), same outputs."""
+    from oracle import vae as ov
+    G = 8
+    blocks = {"mid": ov.MidBlock(64, G), "down": ov.DownEncoderBlock2D(32, 64, 2, G, True), "down_last": ov.DownEncoderBlock2D(64, 64, 2, G, False),
+              "up": ov.UpDecoderBlock2D(64, 32, 3, G, True), "up_last": ov.UpDecoderBlock2D(32, 32, 3, G, False)}
+    with torch.no_grad():
+        for name, blk in blocks.items():
+            pre = f"vae.{name}.sd."
+            blk.eval().load_state_dict({k[len(pre):]: v for k, v in t.items() if k.startswith(pre)})          # strict: same keys
+            y = blk(t[f"vae.{name}.x"])
+            assert y.shape == t[f"vae.{name}.y"].shape, name
+            assert _rel(y, t[f"vae.{name}.y"]) <= PIN_TOL, (name, _rel(y, t[f"vae.{name}.y"]))
+    assert t["vae.down.y"].shape[-2:] == (6, 5) and t["vae.up.y"].shape[-2:] == (12, 10)     # pad(0,1,0,1)+s2 p0; nearest x2
+
+
+def test_oracle_vae_blocks_match_reference_code_golden():
+    t, _ = _load("reference_unet_tiny.safetensors")
+    _check_vae_blocks_against_reference_fixture(t)
+
+
 def test_oracle_unets_match_reference_code_golden():
     """oracle TryonNet / GarmentNet == the reference's own UNet2DConditionModel forwards (committed fixture)."""
     t, meta = _load("reference_unet_tiny.safetensors")
