@@ -68,6 +68,12 @@ def main():
     rec = os.environ.get("IDMVTON_DROPIN_RECORD")
     if rec:
         _install_recorder(rec)
+    # input / output pipeline: under a multi-process launcher every rank iterates its own shard of the script's
+    # (unsharded, shuffle=False) DataLoader; result images are encoded and written on worker threads behind the next pipeline call
+    from idm_vton_amd import io as pio
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    pio.shard_dataloaders(rank, world)
+    os.environ.setdefault("IDMVTON_ASYNC_SAVE", "1")
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name="__main__")
 

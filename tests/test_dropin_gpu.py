@@ -41,3 +41,62 @@ def test_inference_py_call_sequence_runs_to_pixels_on_the_hip_engine(tmp_path):
         assert a.shape == (256, 256, 3) and a.std() > 1.0                                       # decoded image with content
         b = np.asarray(Image.open(os.path.join(out2, n)).convert("RGB"), dtype=np.float32)
         assert np.array_equal(a, b)
+
+
+# ---- the reference's UNMODIFIED scripts, to pixels on the MI355X -----------------------------------------------------------
+# /root/reference does not exist on the GPU box and reference sources are never committed; tools/gpu_real_scripts.sh puts an
+# untracked scratch copy of the two scripts under .scratch_ref/ for ONE gpurun call and deletes it afterwards (log: profiles/).
+def _ref_script(name):
+    for d in (os.environ.get("IDMVTON_REFERENCE", ""), "/root/reference", os.path.join(ROOT, ".scratch_ref")):
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+def _launch(script, args, cwd, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "IDMVTON_DROPIN_RECORD")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_launcher.py"), script] + args, capture_output=True, text=True,
+                          env=env, cwd=cwd, timeout=timeout)
+
+
+@pytest.mark.skipif(_ref_script("inference.py") is None, reason="no copy of the reference's inference.py on this box")
+def test_unmodified_inference_py_produces_pixels_on_the_mi355x(tmp_path):
+    """inference.py:316-329 (from_pretrained of every component), :397-414 (pipe(...)), :415-419 (save) -- the script itself, on
+    the HIP engine: CLIP towers, Resampler, VAE encodes, 4 denoising steps, decode, JPEG."""
+    from tests.test_dropin_cpu import _make_assets
+    from PIL import Image
+    ck, dd = _make_assets(tmp_path)
+    out = str(tmp_path / "out")
+    r = _launch(_ref_script("inference.py"), ["--pretrained_model_name_or_path", ck, "--data_dir", dd, "--width", "256", "--height", "256",
+                                              "--num_inference_steps", "4", "--output_dir", out, "--test_batch_size", "2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    assert sorted(os.listdir(out)) == ["00000_00.jpg", "00001_00.jpg"]
+    for n in os.listdir(out):
+        a = np.asarray(Image.open(os.path.join(out, n)).convert("RGB"), dtype=np.float32)
+        assert a.shape == (256, 256, 3) and a.std() > 1.0
+
+
+@pytest.mark.skipif(_ref_script("inference_dc.py") is None, reason="no copy of the reference's inference_dc.py on this box")
+def test_unmodified_inference_dc_py_produces_pixels_on_the_mi355x(tmp_path):
+    """SURVEY.md 8f-2 / BASELINE.json configs[4]'s data path: DresscodeTestDataset + get_agnostic (inference_dc.py:96-352), the
+    hub id "yisol/IDM-VTON-DC" (:391) resolved relative to the run directory, upper_body."""
+    from tests.test_dropin_cpu import _make_assets
+    from PIL import Image
+    ck, _ = _make_assets(tmp_path, n=1)
+    dd = str(tmp_path / "dc")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_dresscode.py"), dd, "--width", "256", "--height", "256"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = tmp_path / "run"
+    (run / "yisol" / "IDM-VTON-DC").mkdir(parents=True)
+    os.symlink(os.path.join(ck, "unet"), str(run / "yisol" / "IDM-VTON-DC" / "unet"))
+    out = str(tmp_path / "out")
+    r = _launch(_ref_script("inference_dc.py"), ["--pretrained_model_name_or_path", ck, "--data_dir", dd, "--width", "256", "--height", "256",
+                                                 "--num_inference_steps", "4", "--output_dir", out, "--test_batch_size", "2",
+                                                 "--category", "upper_body"], str(run))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    assert sorted(os.listdir(out)) == ["000000_0.jpg", "000001_0.jpg"]
+    for n in os.listdir(out):
+        a = np.asarray(Image.open(os.path.join(out, n)).convert("RGB"), dtype=np.float32)
+        assert a.shape == (256, 256, 3) and a.std() > 1.0

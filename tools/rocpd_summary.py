@@ -1,7 +1,8 @@
 """Summarise a rocprofv3 rocpd SQLite database (`*_results.db`) into a short text table (names truncated).
 Usage: python tools/rocpd_summary.py <results.db> [--by-grid] [--match substr]  > profiles/<name>.txt
-       python tools/rocpd_summary.py <results.db> --timeline   : GPU busy / idle inside the denoising window (first pack_input ..
-       last cfg_step of the LAST pipeline call): span, union of kernel intervals, sum of durations, idle gaps by size"""
+       python tools/rocpd_summary.py <results.db> --timeline [--steps-per-call 30] : GPU busy / idle inside the denoising loop of the
+       LAST pipeline call (trace `bench.py --no-roofline` so that this is a timed hipGraph call): span, union of kernel
+       intervals, sum of durations, idle gaps by size"""
 import re
 import sqlite3
 import sys
@@ -16,27 +17,23 @@ def short(name):
     return name[:70]
 
 
-def timeline(db):
+def timeline(db, steps_per_call=30):
+    """Busy / idle of the LAST pipeline call's denoising loop: the window from the pack_input of its first step to the end of its
+    last cfg_step (`steps_per_call` cfg_step kernels back from the end).  Run the traced command with --no-roofline so that the last
+    call is a TIMED call of the benchmarked form (hipGraph replay, two streams), not the instrumented eager replica of the roofline
+    leg (whose per-launch event records open a 5-10 us gap after every kernel)."""
     c = sqlite3.connect(db)
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
     packs = [i for i, r in enumerate(rows) if "pack_input_kernel" in r[0]]
     cfgs = [i for i, r in enumerate(rows) if "cfg_step_kernel" in r[0]]
-    if not packs or not cfgs:
+    if len(cfgs) < steps_per_call or not packs:
         print("no denoising window found"); return
-    # the last pipeline call: walk back from the last cfg_step to the pack_input that starts its run of steps
     hi = cfgs[-1]
-    nsteps = 1
-    # contiguous run of steps: every cfg_step is followed within 50 launches by the next pack_input
-    j = len(packs) - 1
-    while j > 0 and packs[j] > cfgs[-1]:
-        j -= 1
-    lo = packs[j]
-    while j > 0 and any(packs[j - 1] < ci < packs[j] for ci in cfgs) and packs[j] - max(ci for ci in cfgs if ci < packs[j]) < 50:
-        j -= 1
-        lo = packs[j]
-        nsteps += 1
-    win = rows[lo:hi + 1]
-    t0, t1 = win[0][1], max(r[2] for r in win)
+    first_cfg = cfgs[-steps_per_call]
+    lo = max(p for p in packs if p < first_cfg)
+    nsteps = steps_per_call
+    t0, t1 = rows[lo][1], rows[hi][2]
+    win = [r for r in rows[lo:] if r[1] < t1]            # includes the side stream's kernels that start inside the window
     busy, cur_s, cur_e, gaps = 0, win[0][1], win[0][2], []
     for _, s_, e_ in win[1:]:
         if s_ > cur_e:
@@ -45,21 +42,27 @@ def timeline(db):
             cur_s, cur_e = s_, e_
         else:
             cur_e = max(cur_e, e_)
-    busy += cur_e - cur_s
-    span, sumdur = t1 - t0, sum(r[2] - r[1] for r in win)
+    busy += min(cur_e, t1) - cur_s
+    span, sumdur = t1 - t0, sum(min(r[2], t1) - r[1] for r in win)
+    fam = {}
+    for n, s_, e_ in win:
+        k = short(n).split("<")[0]
+        fam[k] = fam.get(k, 0) + (min(e_, t1) - s_)
     print(f"# {db}")
-    print(f"denoising window of the last call: {nsteps} steps, {len(win)} kernels, span {span / 1e6:.2f} ms = {span / 1e6 / nsteps:.2f} ms/step")
+    print(f"denoising loop of the last call: {nsteps} steps, {len(win)} kernels, span {span / 1e6:.2f} ms = {span / 1e6 / nsteps:.2f} ms/step")
     print(f"  GPU busy (union of kernel intervals) {busy / 1e6:.2f} ms = {100 * busy / span:.1f} % of span; idle {100 * (span - busy) / span:.1f} %")
     print(f"  sum of kernel durations {sumdur / 1e6:.2f} ms = {sumdur / busy:.2f} x busy time (> 1: kernels of the two streams overlap)")
     for lo_us, hi_us in ((0, 2), (2, 5), (5, 10), (10, 50), (50, 1e9)):
         g = [x for x in gaps if lo_us * 1e3 <= x < hi_us * 1e3]
         print(f"  idle gaps {lo_us:>3}-{hi_us if hi_us < 1e9 else 'inf':>3} us: {len(g):6d} gaps, {sum(g) / 1e6:8.3f} ms")
+    print("  kernel time by family inside the window (ms per step): " + ", ".join(f"{k} {v / 1e6 / nsteps:.2f}" for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:8]))
 
 
 def main():
     db = sys.argv[1]
     if "--timeline" in sys.argv:
-        return timeline(db)
+        n = int(sys.argv[sys.argv.index("--steps-per-call") + 1]) if "--steps-per-call" in sys.argv else 30
+        return timeline(db, n)
     by_grid = "--by-grid" in sys.argv
     match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else None
     c = sqlite3.connect(db)
