@@ -37,6 +37,8 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
+    float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group)
+    const float* ln_rowstats; const float* ln_colvec; int ln_parts; float ln_eps;   // consumer: LayerNorm folded into this GEMM
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -150,7 +152,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 continue;
             }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni) {
+                float rs1 = 0.f, rs2 = 0.f;                // LayerNorm row statistics of the values stored below (this lane: 16 of the 32 columns)
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     float v[8];
@@ -199,8 +202,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
                         *(v8*)(out + (size_t)m * p.ldo + n) = o;
+                        if (p.rowstats_out) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; rs1 += f; rs2 += f * f; }
+                        }
                     }
                 }
+                if (p.rowstats_out) {                      // block-uniform; N % 32 == 0, so the whole 32-column group is inside N
+                    rs1 = xhalf_sum(rs1); rs2 = xhalf_sum(rs2);    // lanes l and l + 32 hold the two column halves of the same row
+                    const int grp32 = (n0 + wn * SN + ni * 32) >> 5;
+                    if (u == 0 && grp32 < p.rs_parts) *(float2*)(p.rowstats_out + ((size_t)m * p.rs_parts + grp32) * 2) = make_float2(rs1, rs2);
+                }
+            }
         }
         return;
     }
@@ -479,6 +492,81 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     }
 
+    if (p.ln_rowstats) {                                 // block-uniform: LayerNorm of the activation operand folded into this GEMM
+        // (a) fold the per-32-column (sum, sum of squares) partials of this tile's BM rows -> (rstd, -rstd*mean) in LDS, fixed order
+        constexpr int NT = NW * 64, TPR = NT / BM;       // threads per row
+        static_assert(TPR >= 1 && TPR * BM == NT, "threads per row");
+        __syncthreads();                                 // every wave is done with the last LDS stage
+        float* scr = (float*)smem;                       // [TPR][BM][2] partial folds, then [BM][2] final at fin
+        float* fin = scr + TPR * BM * 2;
+        {
+            const int tid = threadIdx.x, r = tid % BM, part = tid / BM;
+            const int P = p.ln_parts, chunk = (P + TPR - 1) / TPR;
+            const int m = m0 + r;
+            float s1 = 0.f, s2 = 0.f;
+            if (m < p.M) {
+                const float2* rs = (const float2*)p.ln_rowstats + (size_t)m * P;
+                const int j1 = (part + 1) * chunk < P ? (part + 1) * chunk : P;
+                for (int j = part * chunk; j < j1; ++j) { const float2 t = rs[j]; s1 += t.x; s2 += t.y; }
+            }
+            scr[(part * BM + r) * 2] = s1; scr[(part * BM + r) * 2 + 1] = s2;
+            __syncthreads();
+            if (tid < BM) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < TPR; ++q) { a1 += scr[(q * BM + tid) * 2]; a2 += scr[(q * BM + tid) * 2 + 1]; }
+                const float invc = 1.0f / (float)(P * 32);
+                const float mean = a1 * invc;
+                float var = a2 * invc - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                const float rstd = rsqrtf(var + p.ln_eps);
+                fin[tid * 2] = rstd; fin[tid * 2 + 1] = -rstd * mean;
+            }
+            __syncthreads();
+        }
+        // (b) acc <- rstd[m] * acc - rstd[m]*mean[m] * s[n] + c[n]
+        const float* cs_ = p.ln_colvec;
+        const float* cc_ = p.ln_colvec + p.N;
+        if constexpr (!TR) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int nb = n0 + wn * SN + ni * 32 + 4 * u;              // register 4g + j <-> column nb + 8g + j
+                float4 s4[4], c4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool ok = nb + 8 * g < p.N;                      // N % 4 == 0
+                    s4[g] = ok ? *(const float4*)(cs_ + nb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    c4[g] = ok ? *(const float4*)(cc_ + nb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[ni][mi][4 * g + 0] = fmaf(acc[ni][mi][4 * g + 0], ab.x, fmaf(ab.y, s4[g].x, c4[g].x));
+                        acc[ni][mi][4 * g + 1] = fmaf(acc[ni][mi][4 * g + 1], ab.x, fmaf(ab.y, s4[g].y, c4[g].y));
+                        acc[ni][mi][4 * g + 2] = fmaf(acc[ni][mi][4 * g + 2], ab.x, fmaf(ab.y, s4[g].z, c4[g].z));
+                        acc[ni][mi][4 * g + 3] = fmaf(acc[ni][mi][4 * g + 3], ab.x, fmaf(ab.y, s4[g].w, c4[g].w));
+                    }
+                }
+            }
+        } else {                                         // D[m][n]: lane <-> column, register 4g + j <-> row 8g + 4u + j
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + wn * SN + ni * 32 + l31;
+                const float sn = n < p.N ? cs_[n] : 0.f, cn = n < p.N ? cc_[n] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 8 * g + 4 * u + j) * 2);
+                            acc[ni][mi][4 * g + j] = fmaf(acc[ni][mi][4 * g + j], ab.x, fmaf(ab.y, sn, cn));
+                        }
+            }
+        }
+    }
     gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane);
 }
 
@@ -621,6 +709,17 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     int variant = 1, bn = 64, bm = 64;
     static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
     if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
+    p.rowstats_out = a->rowstats_out; p.rs_parts = a->N / 32;
+    p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec; p.ln_parts = a->ln_parts; p.ln_eps = a->ln_eps;
+    if (a->rowstats_out) {
+        CHECK_ARG(a->N % 32 == 0 && !geglu && !a->vt && a->out && p.wide && !(a->io_flags & IDMVTON_IO_OUT_F32) && ((uintptr_t)a->rowstats_out & 7) == 0,
+                  IDMVTON_E_ARG, "gemm_conv: rowstats_out needs N %% 32 == 0 (N=%d), the plain 16-byte epilogue, a 16-bit out", a->N);
+    }
+    if (a->ln_rowstats) {
+        CHECK_ARG(a->ln_colvec && a->ln_parts > 0 && a->ln_parts * 32 == a->seg[0].len && a->nseg == 1 && a->ln_eps > 0.f &&
+                  ((uintptr_t)a->ln_rowstats & 7) == 0 && ((uintptr_t)a->ln_colvec & 15) == 0,
+                  IDMVTON_E_ARG, "gemm_conv: folded LayerNorm needs one K segment of ln_parts*32 = K columns (parts=%d, K=%d) and ln_colvec", a->ln_parts, a->Ktot);
+    } else CHECK_ARG(!a->ln_colvec, IDMVTON_E_ARG, "gemm_conv: ln_colvec without ln_rowstats");
     p.res32 = (a->io_flags & IDMVTON_IO_RES_F32) ? 1 : 0;
     p.out32 = (a->io_flags & IDMVTON_IO_OUT_F32) ? 1 : 0;
     if (p.res32 || p.out32) {

@@ -88,9 +88,12 @@ class SegSpec:
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, quick_gelu=False, vt=None,
-              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False):
+              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, rowstats_out=None, ln=None):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
     fp32 residual stream: a float32 `res` is read as fp32; out_f32=True (or a float32 `out`) writes fp32 (io_flags).
+    LayerNorm folded into the GEMMs around it: rowstats_out = fp32 [M][N/32][2] written by the PRODUCER of a hidden state (sum, sum of
+    squares per 32-column group of the stored values); ln = (rowstats, colvec fp32 [2][N] {s, c}, eps) on the CONSUMER, whose weights
+    carry gamma (see ln_fold_weights).
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
     kernel's key order (see key_order()), False as a plain transpose."""
     a = ffi.GemmConvArgs()
@@ -123,6 +126,10 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.colscale_n, a.colscale = colscale_n, colscale
+    a.rowstats_out = _ptr(rowstats_out)
+    if ln is not None:
+        rs, colvec, eps = ln
+        a.ln_rowstats, a.ln_colvec, a.ln_parts, a.ln_eps = _ptr(rs), _ptr(colvec), Ktot // 32, eps
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))
@@ -135,6 +142,14 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     obytes = (M * (N // 2 if geglu else N)) * (out.element_size() if out is not None else esz) + (M * N * res.element_size() if res is not None else 0)
     _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
+
+
+def ln_fold_weights(w, gamma, beta):
+    """LayerNorm folded into the Linear that consumes it: LN(x) W^T = rstd*(x (gamma*W)^T) - rstd*mean*s + c.  Returns
+    (gamma-scaled weights in w's dtype, colvec fp32 [2][N] = {s[n] = sum_k of the STORED scaled weights, c[n] = sum_k beta[k] W[n][k]})."""
+    wf = w.float()
+    ws = (wf * gamma.float()[None, :]).to(w.dtype).contiguous()
+    return ws, torch.stack([ws.float().sum(1), wf @ beta.float()]).contiguous()
 
 
 def key_order_index(n, device=None):

@@ -47,7 +47,7 @@ class _Conv:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False):
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, fuse_ln=True):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         # stream_f32: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
         # attentionhacked_tryon.py:348,384,412) stays fp32 from proj_in to the last block's ff.net.2, whose output is rounded once
@@ -55,6 +55,12 @@ class HipUNet:
         # measured at full size the option lowers the latent error by 10-35 % for 2.4 % of throughput --
         # operand rounding inside the branches, not the stream, is what bf16 storage costs.
         self.stream_f32 = bool(stream_f32)
+        # fuse_ln: norm1 / norm2 / norm3 of every BasicTransformerBlock folded into the GEMMs on either side (gemm_conv rowstats_out /
+        # ln_*): the to_out / ff.net.2 / proj_in epilogue emits the row statistics of the hidden state it writes, the to_q|k|v /
+        # attn2.to_q / GEGLU projection runs on the raw hidden state with gamma folded into its weights.  210 LayerNorm launches per
+        # TryonNet forward disappear (GarmentNet keeps norm1: its output is the exported feature).  Needs the 16-bit stream.
+        self.fuse_ln = bool(fuse_ln) and not self.stream_f32
+        self._rowstats = {}
         self.topo = unet_topology(cfg)
         sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items() if not k.startswith("encoder_hid_proj.")}
         self.sd = sd
@@ -94,6 +100,12 @@ class HipUNet:
                 if self.tryon:
                     d["kv_ip"] = torch.cat([sd[f"{b}.attn2.processor.to_k_ip.weight"], sd[f"{b}.attn2.processor.to_v_ip.weight"]]).contiguous()
                 d["ff1_w"], d["ff1_b"] = interleave_geglu(sd[f"{b}.ff.net.0.proj.weight"], sd[f"{b}.ff.net.0.proj.bias"])
+                if self.fuse_ln:
+                    if self.tryon:                            # GarmentNet materialises norm1 (the exported feature): its QKV stays plain
+                        d["kv_plain"] = d["qkv"][ch:].clone()   # the garment features are already normalised: unscaled to_k | to_v
+                        d["qkv"], d["qkv_cv"] = ops.ln_fold_weights(d["qkv"], sd[f"{b}.norm1.weight"], sd[f"{b}.norm1.bias"])
+                    d["q2_w"], d["q2_cv"] = ops.ln_fold_weights(sd[f"{b}.attn2.to_q.weight"], sd[f"{b}.norm2.weight"], sd[f"{b}.norm2.bias"])
+                    d["ff1_w"], d["ff1_cv"] = ops.ln_fold_weights(d["ff1_w"], sd[f"{b}.norm3.weight"], sd[f"{b}.norm3.bias"])
                 d["p"] = b
                 blocks.append(d)
             self.tf[p] = dict(blocks=blocks, ch=ch, heads=heads)
@@ -219,18 +231,23 @@ class HipUNet:
         dt, dev = self.dtype, self.device
         M = B * N
         feat = None
+        fuse = self.fuse_ln
+        rs = self._rowstats_buf(M, C) if fuse else None          # row statistics of the current hidden state (written by its producer)
         if not self.tryon:                                       # exported norm1 output (garmnet :321-322)
             fb = garment.get("feats_buf") if garment else None
             feat = fb[len(feats_out)].view(M, C) if fb is not None else torch.empty(M, C, dtype=dt, device=dev)
-        n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
-        if feat is not None:
-            feats_out.append(feat.view(B, N, C))
-            if stop is not None and len(feats_out) >= stop:
-                return None                              # GarmentNet: everything after the last export is dead compute
         qk = torch.empty(M, 2 * C, dtype=dt, device=dev)
         vt = torch.empty(B, C, N, dtype=dt, device=dev)
         # q columns leave the GEMM multiplied by softmax_scale * log2(e) (fp32, before the one rounding to the storage dtype)
-        ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE)
+        if fuse and self.tryon:                                  # norm1 folded into the QKV projection
+            ops.linear(hs, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE, ln=(rs, blk["qkv_cv"], 1e-5))
+        else:
+            n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
+            if feat is not None:
+                feats_out.append(feat.view(B, N, C))
+                if stop is not None and len(feats_out) >= stop:
+                    return None                          # GarmentNet: everything after the last export is dead compute
+            ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE)
         segs = [dict(k=qk[:, C:], vt=vt, nk=N, ldk=2 * C, ldvt=N)]
         if self.tryon:
             if garment.get("kv") is not None:                   # K / V^T of the garment tokens projected ahead of time
@@ -241,16 +258,19 @@ class HipUNet:
                 Bg = g.shape[0]
                 kg = torch.empty(Bg * N, C, dtype=dt, device=dev)
                 vtg = torch.empty(Bg, C, N, dtype=dt, device=dev)
-                ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
+                ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
             garment["idx"] += 1
             segs.append(dict(k=kg, vt=vtg, nk=N, ldk=C, ldvt=N, b0=B - Bg))
         att = torch.empty(M, C, dtype=dt, device=dev)
         ops.attention(qk, att, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C, q_prescaled=True)
         f32 = hs.dtype == torch.float32                          # the fp32 residual stream (see __init__)
-        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32)
+        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
         # cross attention
-        n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
-        q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
+        if fuse:                                                 # norm2 folded into attn2.to_q
+            q2 = ops.linear(hs, blk["q2_w"], ln=(rs, blk["q2_cv"], 1e-5))
+        else:
+            n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+            q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
         kv = ctx["kv"][p]
         att2 = torch.empty(M, C, dtype=dt, device=dev)
         seg_t = dict(k=kv["kt"], vt=kv["vtt"], nk=ctx["nt"], ldk=C, ldvt=ctx["rt"], k_rows=ctx["rt"])
@@ -259,19 +279,32 @@ class HipUNet:
             ops.attention(q2, att2, [seg_t, seg_i], heads, mode=ffi.ATTN_CROSS, ip_scale=self.ip_scale, B=B, Nq=N, ldq=C, ldo=C)
         else:
             ops.attention(q2, att2, [seg_t], heads, B=B, Nq=N, ldq=C, ldo=C)
-        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32)
+        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
         # feed-forward (GEGLU fused into the first GEMM's epilogue)
-        n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
-        gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
-        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs, out_f32=f32 and not last)
+        if fuse:                                                 # norm3 folded into the GEGLU projection
+            gg = ops.linear(hs, blk["ff1_w"], bias=blk["ff1_b"], geglu=True, ln=(rs, blk["ff1_cv"], 1e-5))
+        else:
+            n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
+            gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
+        # the next block's norm1 reads this output's row statistics (TryonNet; GarmentNet runs norm1 as a kernel: it is the exported feature)
+        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs, out_f32=f32 and not last,
+                        rowstats_out=rs if (fuse and self.tryon and not last) else None)
         return hs
+
+    def _rowstats_buf(self, M, C):
+        """fp32 [M][C/32][2] scratch for the LayerNorm row statistics (producer GEMM -> consumer GEMM), one per shape."""
+        key = (M, C)
+        if key not in self._rowstats:
+            self._rowstats[key] = torch.empty(M * (C // 32) * 2, dtype=torch.float32, device=self.device)
+        return self._rowstats[key]
 
     def _transformer(self, p, x, B, H, W, ctx, garment, feats_out, stop_after_feats=None):
         """Transformer2DModel (src/transformerhacked_tryon.py:246-467), NHWC so no permutes."""
         sd, tf = self.sd, self.tf[p]
         C, N = tf["ch"], H * W
         g = self._gn(x, None, p + ".norm", 1e-6, False)
-        hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32)
+        hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32,
+                        rowstats_out=self._rowstats_buf(B * N, C) if (self.fuse_ln and self.tryon) else None)
         for blk in tf["blocks"]:
             hs = self._block(blk, hs, B, N, C, ctx, garment, feats_out, stop_after_feats, last=blk is tf["blocks"][-1])
             if hs is None:
@@ -295,7 +328,7 @@ class HipUNet:
             else:
                 kg = torch.empty(Bg * N, C, dtype=self.dtype, device=self.device)
                 vtg = torch.empty(Bg, C, N, dtype=self.dtype, device=self.device)
-            ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
+            ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
             res.append((kg, vtg))
         return res
 

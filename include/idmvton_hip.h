@@ -90,6 +90,16 @@ typedef struct {
                                     (src/attentionhacked_tryon.py:348,384,412: three `+ hidden_states` per block, 210 per TryonNet forward) is
                                     kept in fp32 between the to_out / ff.net.2 epilogues and the next LayerNorm instead of being rounded to
                                     16 bits after every add; both need the 16-byte epilogue (all strides / N multiples of 8).  0 = off. */
+    /* LayerNorm folded into the GEMMs on either side of it (src/attentionhacked_tryon.py:310,358,390: norm1/2/3 feed to_q|k|v, attn2.to_q,
+       ff.net.0.proj).  LN(x).W^T = rstd[m] * (x . (gamma*W)^T)[m][n] - rstd[m]*mean[m]*s[n] + c[n],  s[n] = sum_k (gamma*W)[n][k],
+       c[n] = sum_k beta[k] W[n][k]: the CONSUMER GEMM runs on the raw hidden state with gamma folded into its weights and applies the
+       per-row / per-column terms to its accumulators before the rest of the epilogue; the per-row statistics come from the PRODUCER
+       GEMM (the to_out / ff.net.2 / proj_in that wrote x), which emits, for every row m and 32-column group j, the (sum, sum of
+       squares) of the values it STORED: rowstats_out[(m*parts + j)*2 + {0,1}], parts = N/32 (N % 32 == 0, plain 16-byte epilogue).
+       The consumer folds the `ln_parts` partials of its rows in a fixed order (deterministic), with ln_C = parts*32 columns and
+       ln_eps; ln_colvec = [2][N] fp32 {s, c}.  No LayerNorm launch, no normalised copy of x in HBM.  All NULL = off. */
+    float* rowstats_out;
+    const float* ln_rowstats; const float* ln_colvec; int32_t ln_parts; float ln_eps;
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */

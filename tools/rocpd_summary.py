@@ -55,6 +55,18 @@ def timeline(db, steps_per_call=30):
     for lo_us, hi_us in ((0, 2), (2, 5), (5, 10), (10, 50), (50, 1e9)):
         g = [x for x in gaps if lo_us * 1e3 <= x < hi_us * 1e3]
         print(f"  idle gaps {lo_us:>3}-{hi_us if hi_us < 1e9 else 'inf':>3} us: {len(g):6d} gaps, {sum(g) / 1e6:8.3f} ms")
+    # what one pipeline call spends OUTSIDE the loop: from the end of the previous call's last cfg_step to this call's first pack_input
+    # = decode + postprocess of call i-1, then preprocessing + 3 VAE encodes + Resampler + step-invariant K/V and embedding tables of call i
+    if len(cfgs) >= steps_per_call + 1:
+        prev_end = rows[cfgs[-steps_per_call - 1]][2]
+        ow = [r for r in rows if r[1] >= prev_end and r[2] <= t0]
+        if ow:
+            ofam = {}
+            for n, s_, e_ in ow:
+                k = short(n).split("<")[0]
+                ofam[k] = ofam.get(k, 0) + (e_ - s_)
+            print(f"outside the loop (decode of the previous call + prepare of this one): span {(t0 - prev_end) / 1e6:.2f} ms, {len(ow)} kernels, "
+                  f"kernel time {sum(ofam.values()) / 1e6:.2f} ms: " + ", ".join(f"{k} {v / 1e6:.2f}" for k, v in sorted(ofam.items(), key=lambda kv: -kv[1])[:10]))
     print("  kernel time by family inside the window (ms per step): " + ", ".join(f"{k} {v / 1e6 / nsteps:.2f}" for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:8]))
 
 
