@@ -59,7 +59,26 @@ __device__ __forceinline__ void swap_cols8(const f32x16& c, const int gp, float 
 // Epilogue shared by every main loop: acc[ni][mi] is the wave's (SN x SM) sub-tile as NI x MI 32x32 accumulators (TR: D[m][n]).
 template <typename T, int NI, int MI, int SN, int SM, bool TR>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[NI][MI], const int m0, const int n0, const int wn, const int wm,
-                                              const int lane) {
+                                              const int lane, const float* fin) {
+    // Folded LayerNorm (fin != nullptr, block-uniform): every accumulator value a of row m, column n becomes
+    //     rstd[m] * a - rstd[m]*mean[m] * s[n] + c[n]        ((rstd, -rstd*mean) = fin[2*row_in_tile ..], s = ln_colvec, c = ln_colvec + N)
+    // right where it is consumed (8 / 4 values at a time, like the bias): a separate pass over the accumulators costs 30-90 extra
+    // registers (the loads get clustered) and spills the 256x256 tile.
+    const float* lcs = p.ln_colvec;
+    const float* lcc = p.ln_colvec + p.N;
+    auto ln8 = [&](float (&v)[8], const float2 ab, const int n) {
+        const float4 s0 = *(const float4*)(lcs + n), s1 = *(const float4*)(lcs + n + 4);
+        const float4 c0 = *(const float4*)(lcc + n), c1 = *(const float4*)(lcc + n + 4);
+        v[0] = fmaf(v[0], ab.x, fmaf(ab.y, s0.x, c0.x)); v[1] = fmaf(v[1], ab.x, fmaf(ab.y, s0.y, c0.y));
+        v[2] = fmaf(v[2], ab.x, fmaf(ab.y, s0.z, c0.z)); v[3] = fmaf(v[3], ab.x, fmaf(ab.y, s0.w, c0.w));
+        v[4] = fmaf(v[4], ab.x, fmaf(ab.y, s1.x, c1.x)); v[5] = fmaf(v[5], ab.x, fmaf(ab.y, s1.y, c1.y));
+        v[6] = fmaf(v[6], ab.x, fmaf(ab.y, s1.z, c1.z)); v[7] = fmaf(v[7], ab.x, fmaf(ab.y, s1.w, c1.w));
+    };
+    auto ln4 = [&](float (&v)[4], const float2 ab, const int n) {
+        const float4 s0 = *(const float4*)(lcs + n), c0 = *(const float4*)(lcc + n);
+        v[0] = fmaf(v[0], ab.x, fmaf(ab.y, s0.x, c0.x)); v[1] = fmaf(v[1], ab.x, fmaf(ab.y, s0.y, c0.y));
+        v[2] = fmaf(v[2], ab.x, fmaf(ab.y, s0.z, c0.z)); v[3] = fmaf(v[3], ab.x, fmaf(ab.y, s0.w, c0.w));
+    };
     typedef typename VT<T>::v4 v4;
     typedef typename VT<T>::v8 v8;
     const int u = lane >> 5, l31 = lane & 31;
@@ -83,6 +102,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         const int b = m / p.vt_tokens;
                         const int tok = m - b * p.vt_tokens + 8 * u;
                         v8 o;
+                        if (fin) {                         // registers 8gp + j <-> rows 16gp + 4u + (j & 3) + 8 (j >> 2) of this 32-row tile
+                            const float sn = lcs[n], cn = lcc[n];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 16 * gp + 4 * u + (j & 3) + 8 * (j >> 2)) * 2);
+                                acc[ni][mi][8 * gp + j] = fmaf(acc[ni][mi][8 * gp + j], ab.x, fmaf(ab.y, sn, cn));
+                            }
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (T)(acc[ni][mi][8 * gp + j] + bv);
                         *(v8*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
@@ -110,6 +137,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     // half-wave contracts in one PV MFMA (QK^T accumulator rows 8g+4u..+3, g = 0,1) are 16 contiguous bytes of V^T
                     if (p.vt_perm) tok = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
                     v4 o;
+                    if (fin) {
+                        const float sn = lcs[n], cn = lcc[n];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 8 * g + 4 * u + j) * 2);
+                            acc[ni][mi][4 * g + j] = fmaf(acc[ni][mi][4 * g + j], ab.x, fmaf(ab.y, sn, cn));
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
                     *(v4*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
@@ -126,6 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const int m = m0 + wm * SM + mi * 32 + l31;
             if (m >= p.M) continue;
             const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
+            const float2 ab = fin ? *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2) : make_float2(1.f, 0.f);
             if (p.mode == IDMVTON_EPI_GEGLU) {
                 if constexpr (NI % 2 == 0) {
 #pragma unroll
@@ -137,6 +173,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                             swap_cols8(acc[2 * pr + 1][mi], gp, gt);
                             const int nh = n0 + wn * SN + pr * 64 + 16 * gp + 8 * u;   // h rows; gate rows are nh + 32
                             if (nh + 32 >= p.N) continue;
+                            if (fin) { ln8(h, ab, nh); ln8(gt, ab, nh + 32); }
                             const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 16 * gp + 8 * u;
                             if (bias) {
                                 const v8 bh = *(const v8*)(bias + nh), bg = *(const v8*)(bias + nh + 32);
@@ -160,6 +197,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     swap_cols8(acc[ni][mi], gp, v);
                     const int n = n0 + wn * SN + ni * 32 + 16 * gp + 8 * u;
                     if (n >= p.N) continue;
+                    if (fin) ln8(v, ab, n);
                     if (bias) {
                         const v8 bb = *(const v8*)(bias + n);
 #pragma unroll
@@ -222,6 +260,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const int m = m0 + wm * SM + mi * 32 + l31;
         if (m >= p.M) continue;
         const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
+        const float2 ab = fin ? *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2) : make_float2(1.f, 0.f);
         if (p.mode == IDMVTON_EPI_GEGLU) {
             if constexpr (NI % 2 == 0) {
 #pragma unroll
@@ -235,6 +274,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float h = acc[2 * pr][mi][4 * g + j], gt = acc[2 * pr + 1][mi][4 * g + j];
+                            if (fin) {
+                                h = fmaf(h, ab.x, fmaf(ab.y, lcs[nh + j], lcc[nh + j]));
+                                gt = fmaf(gt, ab.x, fmaf(ab.y, lcs[nh + 32 + j], lcc[nh + 32 + j]));
+                            }
                             if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
                             o[j] = (T)(h * gelu_erf(gt));
                         }
@@ -252,6 +295,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                if (fin) ln4(v, ab, n);
                 if (bias) {
                     const v4 bb = *(const v4*)(bias + n);
 #pragma unroll
@@ -492,22 +536,32 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     }
 
+    const float* fin = nullptr;                          // LDS: (rstd, -rstd*mean) of this tile's rows, nullptr = no folded LayerNorm
     if (p.ln_rowstats) {                                 // block-uniform: LayerNorm of the activation operand folded into this GEMM
-        // (a) fold the per-32-column (sum, sum of squares) partials of this tile's BM rows -> (rstd, -rstd*mean) in LDS, fixed order
+        // fold the per-32-column (sum, sum of squares) partials of this tile's BM rows -> (rstd, -rstd*mean) in LDS, fixed order
         constexpr int NT = NW * 64, TPR = NT / BM;       // threads per row
         static_assert(TPR >= 1 && TPR * BM == NT, "threads per row");
         __syncthreads();                                 // every wave is done with the last LDS stage
-        float* scr = (float*)smem;                       // [TPR][BM][2] partial folds, then [BM][2] final at fin
-        float* fin = scr + TPR * BM * 2;
+        float* scr = (float*)smem;                       // [TPR][BM][2] partial folds, then [BM][2] final at fin_
+        float* fin_ = scr + TPR * BM * 2;
+        fin = fin_;
         {
             const int tid = threadIdx.x, r = tid % BM, part = tid / BM;
             const int P = p.ln_parts, chunk = (P + TPR - 1) / TPR;
             const int m = m0 + r;
             float s1 = 0.f, s2 = 0.f;
             if (m < p.M) {
+                // eight partials in flight per batch: a rolled `load; add` loop is one dependent L2 round trip per partial (20-40 of
+                // them, 10-20 us per tile); the summation order is unchanged
                 const float2* rs = (const float2*)p.ln_rowstats + (size_t)m * P;
                 const int j1 = (part + 1) * chunk < P ? (part + 1) * chunk : P;
-                for (int j = part * chunk; j < j1; ++j) { const float2 t = rs[j]; s1 += t.x; s2 += t.y; }
+                for (int j = part * chunk; j < j1; j += 8) {
+                    float2 t[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t[q] = j + q < j1 ? rs[j + q] : make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { s1 += t[q].x; s2 += t[q].y; }
+                }
             }
             scr[(part * BM + r) * 2] = s1; scr[(part * BM + r) * 2 + 1] = s2;
             __syncthreads();
@@ -520,54 +574,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
                 float var = a2 * invc - mean * mean;
                 var = var > 0.f ? var : 0.f;
                 const float rstd = rsqrtf(var + p.ln_eps);
-                fin[tid * 2] = rstd; fin[tid * 2 + 1] = -rstd * mean;
+                fin_[tid * 2] = rstd; fin_[tid * 2 + 1] = -rstd * mean;
             }
             __syncthreads();
         }
-        // (b) acc <- rstd[m] * acc - rstd[m]*mean[m] * s[n] + c[n]
-        const float* cs_ = p.ln_colvec;
-        const float* cc_ = p.ln_colvec + p.N;
-        if constexpr (!TR) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int nb = n0 + wn * SN + ni * 32 + 4 * u;              // register 4g + j <-> column nb + 8g + j
-                float4 s4[4], c4[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const bool ok = nb + 8 * g < p.N;                      // N % 4 == 0
-                    s4[g] = ok ? *(const float4*)(cs_ + nb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    c4[g] = ok ? *(const float4*)(cc_ + nb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[ni][mi][4 * g + 0] = fmaf(acc[ni][mi][4 * g + 0], ab.x, fmaf(ab.y, s4[g].x, c4[g].x));
-                        acc[ni][mi][4 * g + 1] = fmaf(acc[ni][mi][4 * g + 1], ab.x, fmaf(ab.y, s4[g].y, c4[g].y));
-                        acc[ni][mi][4 * g + 2] = fmaf(acc[ni][mi][4 * g + 2], ab.x, fmaf(ab.y, s4[g].z, c4[g].z));
-                        acc[ni][mi][4 * g + 3] = fmaf(acc[ni][mi][4 * g + 3], ab.x, fmaf(ab.y, s4[g].w, c4[g].w));
-                    }
-                }
-            }
-        } else {                                         // D[m][n]: lane <-> column, register 4g + j <-> row 8g + 4u + j
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int n = n0 + wn * SN + ni * 32 + l31;
-                const float sn = n < p.N ? cs_[n] : 0.f, cn = n < p.N ? cc_[n] : 0.f;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 8 * g + 4 * u + j) * 2);
-                            acc[ni][mi][4 * g + j] = fmaf(acc[ni][mi][4 * g + j], ab.x, fmaf(ab.y, sn, cn));
-                        }
-            }
-        }
     }
-    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane);
+    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, fin);
 }
 
 // Tile configurations.  id = the `variant` field of tile_hint (bits 28..31); BN/BM in bits 16..27 / 0..15.
@@ -736,6 +748,9 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
             const int n_ = cand[i][0], m_ = cand[i][1];
             if (geglu && n_ < 128) continue;
             if (a->vt && a->vt_n0 % n_ != 0) continue;
+            // a tile wider than the (64-rounded) problem wastes its surplus columns' MFMAs: N = 128 on the 256-column tile ran the
+            // VAE's full-resolution 128-channel convolutions at half rate (profiles/r03_v2_prof_default_kernel_stats_by_grid.txt)
+            if (i < 4 && (n_ > ((a->N + 63) & ~63) || m_ > ((a->M + 63) & ~63))) continue;
             bn = n_; bm = m_;
             if ((long)((a->N + n_ - 1) / n_) * ((a->M + m_ - 1) / m_) >= 200) break;
         }

@@ -47,7 +47,7 @@ class _Conv:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, fuse_ln=True):
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, fuse_ln=False):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         # stream_f32: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
         # attentionhacked_tryon.py:348,384,412) stays fp32 from proj_in to the last block's ff.net.2, whose output is rounded once
@@ -59,6 +59,10 @@ class HipUNet:
         # ln_*): the to_out / ff.net.2 / proj_in epilogue emits the row statistics of the hidden state it writes, the to_q|k|v /
         # attn2.to_q / GEGLU projection runs on the raw hidden state with gamma folded into its weights.  210 LayerNorm launches per
         # TryonNet forward disappear (GarmentNet keeps norm1: its output is the exported feature).  Needs the 16-bit stream.
+        # OFF by default -- measured (profiles/r03_lnfold_probe.log, r03_bench_ab_lnfold_*.json): the producer side is free (+1 us) and
+        # attn2.to_q gains (LayerNorm 10.2 us -> +4.6 us), but every consumer TILE re-folds its rows' partials and re-reads s / c, which
+        # costs the many-tile consumers more than the LayerNorm launch they replace (QKV +12 us, GEGLU +16.5 us at M = 3072):
+        # 1.45 vs 1.50 images/s.  Results are identical in tolerance either way (tests/kernel_checks.py::check_ln_fold).
         self.fuse_ln = bool(fuse_ln) and not self.stream_f32
         self._rowstats = {}
         self.topo = unet_topology(cfg)
@@ -235,7 +239,7 @@ class HipUNet:
         rs = self._rowstats_buf(M, C) if fuse else None          # row statistics of the current hidden state (written by its producer)
         if not self.tryon:                                       # exported norm1 output (garmnet :321-322)
             fb = garment.get("feats_buf") if garment else None
-            feat = fb[len(feats_out)].view(M, C) if fb is not None else torch.empty(M, C, dtype=dt, device=dev)
+            feat = fb[len(feats_out)][:B].view(M, C) if fb is not None else torch.empty(M, C, dtype=dt, device=dev)
         qk = torch.empty(M, 2 * C, dtype=dt, device=dev)
         vt = torch.empty(B, C, N, dtype=dt, device=dev)
         # q columns leave the GEMM multiplied by softmax_scale * log2(e) (fp32, before the one rounding to the storage dtype)
@@ -324,7 +328,7 @@ class HipUNet:
         for i, (blk, g) in enumerate(zip(self.block_order, feats)):
             Bg, N, C = g.shape
             if out is not None:
-                kg, vtg = out[i]
+                kg, vtg = out[i][0][:Bg * N], out[i][1][:Bg]     # the persistent set is sized for the largest block
             else:
                 kg = torch.empty(Bg * N, C, dtype=self.dtype, device=self.device)
                 vtg = torch.empty(Bg, C, N, dtype=self.dtype, device=self.device)

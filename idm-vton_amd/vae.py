@@ -138,8 +138,19 @@ class HipVAE:
 
     def encode_sample(self, image_nchw, noise, scale=None):
         """`vae.encode(x).latent_dist.sample() * scaling_factor` with caller-supplied N(0,1) noise [B][4][h][w] fp32."""
-        mom, h, w = self.encode_moments(image_nchw)
-        return ops.vae_sample(mom, noise.contiguous(), self.cfg.scaling_factor if scale is None else scale)
+        B, _, H, W = image_nchw.shape
+        # the kernels address every tensor through 32-bit buffer descriptors (< 2 GiB): the largest activation of the encoder is
+        # B x H x W x 128 channels x 2 bytes, so large batches run in chunks (per image the arithmetic does not depend on the chunking)
+        bmax = max(1, (2 ** 31 - 1) // (H * W * self.cfg.block_out_channels[0] * 2))
+        sc = self.cfg.scaling_factor if scale is None else scale
+        if B <= bmax:
+            mom, h, w = self.encode_moments(image_nchw)
+            return ops.vae_sample(mom, noise.contiguous(), sc)
+        out = []
+        for b0 in range(0, B, bmax):
+            mom, h, w = self.encode_moments(image_nchw[b0:b0 + bmax])
+            out.append(ops.vae_sample(mom, noise[b0:b0 + bmax].contiguous(), sc))
+        return torch.cat(out)
 
     def decode(self, z_nchw):
         """z: fp32 NCHW latents (already divided by scaling_factor) -> image fp32 NCHW (pre-postprocess)."""

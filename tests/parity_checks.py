@@ -7,13 +7,13 @@ from tests import parity_utils as pu
 
 @torch.no_grad()
 def run(kind="tiny", dtype=torch.float16, B=1, H=128, W=128, steps=4, scheduler="ddpm", use_graph=False, device="cuda",
-        overlap=False):
+        overlap=False, unet_kw=None):
     from idm_vton_amd import ops
     from idm_vton_amd.pipeline import TryonEngine
     from oracle import pipeline as opipe
     from oracle.scheduler import Scheduler
 
-    m = pu.build(kind, dtype, device)
+    m = pu.build(kind, dtype, device, unet_kw=unet_kw)
     o_t, o_g, o_v = m["oracle"]
     p_t, p_g, p_v, p_r = m["product"]
     inp = pu.make_inputs(B, H, W, m["xd"], m["pooled"], m["enc_dim"], steps, dtype)

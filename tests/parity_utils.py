@@ -16,7 +16,7 @@ MID = dict(block_out_channels=(320, 640, 1280), transformer_layers_per_block=(1,
            encoder_hid_dim=256, resampler=dict(dim=256, depth=1, dim_head=64, heads=4, num_queries=16, ff_mult=4))
 
 
-def build(kind, dtype, device, seed=0):
+def build(kind, dtype, device, seed=0, unet_kw=None):
     """-> dict(oracle=(unet, garm, vae), product=(HipUNet, HipUNet, HipVAE, HipResampler), cfgs)"""
     from idm_vton_amd import config as pc
     from idm_vton_amd.resampler import HipResampler
@@ -42,8 +42,8 @@ def build(kind, dtype, device, seed=0):
     o_v.load_state_dict(sd_v)
     prod = None
     if device != "cpu":
-        p_t = HipUNet(tcfg, sd_t, dtype, device)
-        p_g = HipUNet(gcfg, sd_g, dtype, device)
+        p_t = HipUNet(tcfg, sd_t, dtype, device, **(unet_kw or {}))
+        p_g = HipUNet(gcfg, sd_g, dtype, device, **(unet_kw or {}))
         p_v = HipVAE(vcfg, sd_v, dtype, device)
         p_r = HipResampler(sd_t, prefix="encoder_hid_proj.", dtype=dtype, device=device, **tcfg.resampler)
         prod = (p_t, p_g, p_v, p_r)

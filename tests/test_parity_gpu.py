@@ -9,7 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float16: dict(stage=4e-3, latents=5e-3, image=1e-2),
+# `image` = the VAE decode of latents that already differ by `latents`: the random-init test VAE (std 0.05 weights, 4 levels) roughly
+# doubles a relative latent difference on top of its own ~2.5e-3 / 2e-2 storage rounding (tests/test_fullsize_parity_gpu.py: decode)
+TOL = {torch.float16: dict(stage=4e-3, latents=5e-3, image=1.5e-2),
        torch.bfloat16: dict(stage=3e-2, latents=4e-2, image=6e-2)}
 
 
@@ -134,3 +136,17 @@ def test_strength_and_no_cfg_branches_match_oracle(case):
         assert pu.relerr(st["latents"], tr["latents0"]) < 2e-3, "start latents (add_noise of the encoded image)"
         lat_p = eng.denoise(st, **kw)
         assert pu.relerr(lat_p, lat_o) <= TOL[dt]["latents"], (case, kw, pu.relerr(lat_p, lat_o))
+
+
+@pytest.mark.parametrize("opt", ["fuse_ln", "stream_f32"])
+def test_engine_options_match_oracle(opt):
+    """The two HipUNet options that are off by default -- LayerNorm folded into the neighbouring GEMMs (fuse_ln) and the fp32
+    residual stream (stream_f32) -- through every stage against the oracle, same bars as the default engine (the kernels behind
+    them are checked tile by tile in tests/kernel_checks.py: check_ln_fold / check_stream_f32)."""
+    from tests import parity_checks
+    for dtype, kw in ((torch.float16, dict()), (torch.bfloat16, dict()), (torch.float16, dict(use_graph=True, overlap=True))):
+        t = TOL[dtype]
+        r = parity_checks.run("tiny", dtype, B=2, H=128, W=128, steps=3, unet_kw={opt: True}, **kw)
+        for k in ("garment_feat_max", "tryon_eps", "tryon_eps_materialised_zeros"):
+            assert r[k] <= t["stage"], (k, r)
+        assert r["latents_final"] <= t["latents"] and r["image"] <= t["image"], r
