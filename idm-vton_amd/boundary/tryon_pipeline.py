@@ -152,11 +152,16 @@ class StableDiffusionXLInpaintPipeline:
     def _hip_clip(self, name):
         """The HIP executor (idm_vton_amd.clip) of a transformers CLIP tower that lives on the GPU: prepared weights are cached and
         rebuilt when the module's parameters change.  None for a module on the CPU or one that is not a transformers CLIP tower
-        (a caller's own encoder is called as is)."""
+        (a caller's own encoder is called as is).  An fp32 tower is executed with bf16 STORAGE and fp32 accumulation (the kernels take
+        16-bit operands; bf16 keeps fp32's exponent range): hidden states differ from an fp32 torch run by bf16 rounding, ~1e-2
+        relative (tests/test_clip_gpu.py), where the reference would have run that module in fp32 -- pass it in fp16 (as inference.py
+        does, :262-274) for fp16 rounding instead."""
         mod = getattr(self, name)
         kind = getattr(getattr(mod, "config", None), "model_type", None)
-        p0 = next(mod.parameters())
-        if kind not in ("clip_text_model", "clip_vision_model") or not p0.is_cuda:
+        if kind not in ("clip_text_model", "clip_vision_model") or not hasattr(mod, "parameters"):
+            return None                                   # a caller's own encoder (any callable): called as is, never inspected
+        p0 = next(mod.parameters(), None)
+        if p0 is None or not p0.is_cuda:
             return None
         ffi.lib()
         key = params_version(mod)
@@ -410,7 +415,8 @@ class StableDiffusionXLInpaintPipeline:
         lat = eng(image=img, mask_image=msk, pose_img=pose, cloth=clo, prompt_embeds=prompt_embeds,
                   negative_prompt_embeds=negative_prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
                   negative_pooled_prompt_embeds=negative_pooled_prompt_embeds, text_embeds_cloth=text_embeds_cloth,
-                  noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=steps_noise, image=n_img),
+                  noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=steps_noise, image=n_img,
+                             latents_given=latents is not None),
                   num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, ip_hidden_states=image_states,
                   strength=strength, image_dtype=prompt_embeds.dtype,
                   scheduler=kind, height=height, width=width, return_latents=True, use_graph=self.use_graph,

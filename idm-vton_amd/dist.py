@@ -44,12 +44,56 @@ def alloc_arena(shapes, dtype, device):
     return flat, views
 
 
-def broadcast_arena(flat, src=0, chunk_elems=1 << 28):
-    """Broadcast a flat weight arena from `src` in <= 512 MiB (bf16) pieces.  No-op for world size 1."""
+_c_comm = None
+
+
+def c_abi_comm():
+    """The RCCL communicator of the C ABI (include/idmvton_hip.h: idmvton_rccl_*), built once: rank 0 draws the ncclUniqueId, the
+    128 bytes travel through the torch.distributed store (any backend), every rank joins.  World size 1 works too (tests)."""
+    global _c_comm
+    if _c_comm is not None:
+        return _c_comm
+    import ctypes as C
+    from . import ffi
+    L = ffi.lib()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    buf = (C.c_char * 128)()
+    if rank == 0 and L.idmvton_rccl_unique_id(buf) != 0:
+        raise RuntimeError(L.idmvton_last_error().decode())
+    box = [bytes(buf)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    comm = C.c_void_p()
+    if L.idmvton_rccl_comm_init(box[0], rank, world, C.byref(comm)) != 0:
+        raise RuntimeError(L.idmvton_last_error().decode())
+    _c_comm = comm
+    return comm
+
+
+def broadcast_arena(flat, src=0, chunk_elems=1 << 28, via=None):
+    """Broadcast a flat weight arena from `src` in <= 512 MiB (bf16) pieces.  No-op for world size 1.
+    via = "torch" (default; torch.distributed.broadcast: backend "nccl" IS RCCL on ROCm, gloo on CPU) or "c_abi" (the C ABI's
+    idmvton_rccl_bcast_arena on its own communicator; also selected by IDMVTON_RCCL_C_ABI=1).  Both move the same bytes."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    via = via or ("c_abi" if os.environ.get("IDMVTON_RCCL_C_ABI") == "1" else "torch")
+    if via == "c_abi" and flat.is_cuda:
+        bcast_c_abi(flat, src, chunk_elems * flat.element_size())
         return
     for o in range(0, flat.numel(), chunk_elems):
         dist.broadcast(flat[o:o + chunk_elems], src=src)
+
+
+def bcast_c_abi(flat, src=0, chunk_bytes=512 << 20):
+    """idmvton_rccl_bcast_arena on the current stream (works for world size 1: RCCL's single-rank broadcast is a local copy)."""
+    import ctypes as C
+    from . import ffi
+    L = ffi.lib()
+    rc = L.idmvton_rccl_bcast_arena(c_abi_comm(), C.c_void_p(flat.data_ptr()), flat.numel() * flat.element_size(), src, chunk_bytes,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError(L.idmvton_last_error().decode())
 
 
 def shard_range(n_items, rank, world):
@@ -79,5 +123,10 @@ def barrier():
 
 def shutdown():
     """Tear the process group down (every rank, after its last collective)."""
+    global _c_comm
+    if _c_comm is not None:
+        from . import ffi
+        ffi.lib().idmvton_rccl_comm_destroy(_c_comm)
+        _c_comm = None
     if dist.is_initialized():
         dist.destroy_process_group()

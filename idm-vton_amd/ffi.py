@@ -85,7 +85,8 @@ STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
            "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles",
-           "idmvton_prefetch", "idmvton_attn_small"]
+           "idmvton_prefetch", "idmvton_attn_small", "idmvton_rccl_unique_id", "idmvton_rccl_comm_init", "idmvton_rccl_bcast_arena",
+           "idmvton_rccl_comm_destroy"]
 
 _lib = None
 
@@ -122,6 +123,12 @@ def lib():
     L.idmvton_groupnorm_stats_doubles.restype = C.c_int
     L.idmvton_prefetch.argtypes = [vp, C.c_uint64, C.c_int, vp]
     L.idmvton_prefetch.restype = C.c_int
+    L.idmvton_rccl_unique_id.argtypes = [vp]
+    L.idmvton_rccl_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.idmvton_rccl_bcast_arena.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]
+    L.idmvton_rccl_comm_destroy.argtypes = [vp]
+    for s in ("idmvton_rccl_unique_id", "idmvton_rccl_comm_init", "idmvton_rccl_bcast_arena", "idmvton_rccl_comm_destroy"):
+        getattr(L, s).restype = C.c_int
     _lib = L
     return L
 

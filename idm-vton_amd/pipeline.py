@@ -61,6 +61,17 @@ class TryonEngine:
         H = height or image.shape[-2]
         W = width or image.shape[-1]
         h, w = H // 8, W // 8
+        # every attention level needs a multiple of 16 tokens (V^T is stored in groups of 16 keys): (H/32)*(W/32) % 16 == 0 for the
+        # three-level SDXL UNets -- say so here instead of failing inside a GEMM launch with a low-level message
+        nlev = len(self.unet.cfg.block_out_channels)
+        if H % 8 or W % 8 or (h % (1 << (nlev - 1))) or (w % (1 << (nlev - 1))) or ((h >> (nlev - 1)) * (w >> (nlev - 1))) % 16:
+            raise ValueError(f"height x width = {H} x {W} is not supported by the HIP attention kernels: the latent {h} x {w} must be divisible "
+                             f"by {1 << (nlev - 1)} and hold a multiple of 16 tokens at the coarsest level (e.g. 256x256, 512x384, 1024x768, 1536x1024)")
+        start_is_given = bool(noise.get("latents_given"))    # the reference's `latents=` argument: used as the start as they are (:880-882)
+        if strength < 1.0 and noise.get("image") is None and not start_is_given:
+            raise ValueError("strength < 1 starts from add_noise(encode(image)): pass the posterior draw of the init-image encode as "
+                             "noise['image'] (the reference's first random draw, tryon_pipeline.py:883-889), or set noise['latents_given'] "
+                             "when noise['latents'] already is the start (the reference's `latents=` argument)")
         sched = StepScheduler(scheduler)
         timesteps = sched.set_timesteps(num_inference_steps)                               # :1561
         init_t = min(int(num_inference_steps * strength), num_inference_steps)             # get_timesteps :987-995
@@ -82,7 +93,7 @@ class TryonEngine:
         init_image = 2.0 * image - 1.0                                                     # preprocess :1588-1591
         mask = (mask_image >= 0.5).float()                                                 # mask_processor :1593-1595
         masked_image = init_image * (mask < 0.5)                                           # :1602
-        if strength == 1.0 or noise.get("image") is None:
+        if strength == 1.0 or start_is_given:
             latents = f32(noise["latents"]) * sched.init_noise_sigma                       # :889-893
         else:                                                                              # image + noise start (:883-891)
             src = init_image if image_dtype is None else init_image.to(image_dtype).float()    # prepare_latents casts the image (:884)
@@ -198,7 +209,7 @@ class TryonEngine:
                     trace.setdefault("step_latents", []).append(st["latents"].clone())
         return st["latents"]
 
-    def _denoise_overlap_eager(self, st):
+    def _denoise_overlap_eager(self, st, trace=None):
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -223,6 +234,8 @@ class TryonEngine:
             for j in range(c):
                 i = s0 + j
                 self._tryon_main(st, st["temb_t"][i], st["coef"][i], self._noise(st, i), sets[cur]["step"][j])
+                if trace is not None:
+                    trace.setdefault("step_latents", []).append(st["latents"].clone())
             free[cur].record(main)
         main.wait_stream(side)
         return st["latents"]
@@ -332,7 +345,7 @@ class TryonEngine:
         """The loop.  Four execution forms with bit-identical results: {serial, two-stream overlap} x {eager, hipGraph replay}."""
         if use_graph:
             return self._denoise_graph(st, overlap, trace)
-        return self._denoise_overlap_eager(st) if overlap else self._denoise_serial_eager(st, trace)
+        return self._denoise_overlap_eager(st, trace) if overlap else self._denoise_serial_eager(st, trace)
 
     @torch.no_grad()
     def decode(self, latents):

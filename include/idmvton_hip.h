@@ -247,6 +247,19 @@ int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream);
  * (No reference counterpart: the reference streams its weights through cuBLAS/cuDNN kernels with no explicit residency.) */
 int idmvton_prefetch(const void* ptr, uint64_t bytes, int blocks, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The path's one collective: start-up broadcast of a packed weight arena from `root` to every rank over RCCL / xGMI.
+ * No reference counterpart: every process of the reference loads every checkpoint itself (inference.py:232-274) and there are no
+ * cross-image collectives.  One process per GPU; rank 0 calls idmvton_rccl_unique_id and ships the 128 bytes to the other ranks by
+ * any side channel (the Python host uses the torch.distributed store); every rank then builds the communicator and calls
+ * idmvton_rccl_bcast_arena on its own copy of the arena (in place; <= chunk_bytes per ncclBroadcast, 0 = 512 MiB), asynchronously
+ * on `stream`.  librccl.so is dlopen'ed on first use: single-GPU users never load it.
+ * ------------------------------------------------------------------------------------------------------------- */
+int idmvton_rccl_unique_id(void* id128);                                  /* out: 128 bytes (ncclUniqueId) */
+int idmvton_rccl_comm_init(const void* id128, int rank, int world, void** comm_out);
+int idmvton_rccl_bcast_arena(void* comm, void* buf, uint64_t bytes, int root, uint64_t chunk_bytes, void* stream);
+int idmvton_rccl_comm_destroy(void* comm);
+
 /* Hardware layout probes (tests/test_probe_gpu.py): run one MFMA / LDS-transpose instruction on caller data. */
 int idmvton_probe_mfma(int which, const void* a, const void* b, float* c, void* stream);
 

@@ -150,3 +150,32 @@ def test_engine_options_match_oracle(opt):
         for k in ("garment_feat_max", "tryon_eps", "tryon_eps_materialised_zeros"):
             assert r[k] <= t["stage"], (k, r)
         assert r["latents_final"] <= t["latents"] and r["image"] <= t["image"], r
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_time_and_added_embeddings_match_oracle(dtype):
+    """SURVEY.md 8a row a13 on its own (src/unet_hacked_tryon.py:1118-1213): Timesteps(flip_sin_to_cos, shift 0) -> time_embedding,
+    the six add_time_ids through Timesteps(256) in the reference's ORDER, concatenated after the pooled text embedding ->
+    add_embedding, summed, and every ResnetBlock2D's time_emb_proj(silu(emb)) -- the engine computes all of it for all timesteps in
+    one table before the loop.  Distinct time-id values and both ends of the schedule, so a flipped sin/cos half, a swapped id or a
+    wrong frequency denominator cannot cancel."""
+    import torch.nn.functional as F
+    from tests import parity_utils as pu
+    m = pu.build("tiny", dtype, "cuda")
+    o_t, o_g, _ = m["oracle"]
+    p_t, p_g, _, _ = m["product"]
+    B2 = 2
+    g = torch.Generator().manual_seed(9)
+    add_text = torch.randn(B2, m["pooled"], generator=g).to(dtype).float()
+    time_ids = torch.tensor([[1024.0, 768.0, 3.0, 17.0, 512.0, 384.0], [96.0, 1536.0, 0.0, 5.0, 640.0, 8.0]])
+    ts = [999, 481, 34, 1]
+    for net_p, net_o, added_p, added_o in ((p_t, o_t, dict(text_embeds=add_text.cuda(), time_ids=time_ids.cuda()), dict(text_embeds=add_text, time_ids=time_ids)),
+                                          (p_g, o_g, None, None)):
+        table = net_p.time_embeddings(ts, B2, added_p).float().cpu()                  # [steps][B][sum of Cout]
+        sample = torch.zeros(B2, 4, 8, 8)
+        for si, t in enumerate(ts):
+            emb = net_o.time_embed(sample, t, added_o)
+            for name, (off, co) in net_p.temb_slices.items():
+                ref = net_o.get_submodule(name).time_emb_proj(F.silu(emb))
+                e = pu.relerr(table[si, :, off:off + co], ref)
+                assert e <= (4e-3 if dtype == torch.float16 else 3e-2), (name, t, e)
