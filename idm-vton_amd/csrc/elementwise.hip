@@ -160,18 +160,23 @@ extern "C" int idmvton_prefetch(const void* ptr, uint64_t bytes, int blocks, voi
 // ---- hardware layout probes: one wave, one instruction, raw per-lane operands in, raw per-lane results out ----
 // which = 0: mfma_f32_32x32x16_bf16   a,b: [64 lanes][8] bf16 ; c: [64 lanes][16] f32
 // which = 1: mfma_f32_32x32x16_f16
+// which = 2: mfma_scale_f32_32x32x64_f8f6f4, A and B fp8 e4m3 (cbsz = blgp = 0), a,b: [64 lanes][32] bytes, unit E8M0 scales (127)
+// which = 3: the same with scale A = 2^-3 (E8M0 byte 124) and scale B = 2^1 (128): D = (A . B) * 2^-2
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 __global__ void probe_mfma_kernel(int which, const void* a, const void* b, float* c) {
     const int lane = threadIdx.x;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (which == 0) acc = VT<bf16_t>::mfma(((const bf16x8*)a)[lane], ((const bf16x8*)b)[lane], acc);
+    else if (which == 2) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(((const i32x8*)a)[lane], ((const i32x8*)b)[lane], acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    else if (which == 3) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(((const i32x8*)a)[lane], ((const i32x8*)b)[lane], acc, 0, 0, 0, 0x7c7c7c7c, 0, (int)0x80808080);
     else acc = VT<f16_t>::mfma(((const f16x8*)a)[lane], ((const f16x8*)b)[lane], acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[lane * 16 + r] = acc[r];
 }
 extern "C" int idmvton_probe_mfma(int which, const void* a, const void* b, float* c, void* stream) {
-    CHECK_ARG(a && b && c && (which == 0 || which == 1), IDMVTON_E_ARG, "probe_mfma: bad args");
+    CHECK_ARG(a && b && c && which >= 0 && which <= 3, IDMVTON_E_ARG, "probe_mfma: bad args");
     hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, which, a, b, c);
     CHECK_LAUNCH("probe_mfma");
     return IDMVTON_OK;
@@ -182,7 +187,7 @@ extern "C" int idmvton_sizeof(const char* name) {
 #define SZ(n) if (!strcmp(name, #n)) return (int)sizeof(n);
     SZ(idmvton_seg) SZ(idmvton_gemm_conv_args) SZ(idmvton_attn_args) SZ(idmvton_layernorm_args)
     SZ(idmvton_groupnorm_args) SZ(idmvton_pack_input_args) SZ(idmvton_cfg_step_args) SZ(idmvton_layout_args)
-    SZ(idmvton_vae_sample_args) SZ(idmvton_softmax_args) SZ(idmvton_attn_small_args)
+    SZ(idmvton_vae_sample_args) SZ(idmvton_softmax_args) SZ(idmvton_attn_small_args) SZ(idmvton_attn_f8_args) SZ(idmvton_quant_f8_args)
 #undef SZ
     return -1;
 }

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_hip.so")   # override: A/B of library builds
 
-F16, BF16, F32 = 0, 1, 2
+F16, BF16, F32, F8E4M3 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS = 0, 1
 IO_RES_F32, IO_OUT_F32 = 1, 2
@@ -71,6 +71,16 @@ class AttnSmallArgs(C.Structure):
                 ("k", vp), ("ldk", i32), ("v", vp), ("ldv", i32), ("out", vp), ("ldo", i32), ("scale", f32), ("causal", i32)]
 
 
+class AttnF8Args(C.Structure):
+    _fields_ = [("out_dtype", i32), ("B", i32), ("heads", i32), ("Nq", i32), ("q8", vp), ("ldq", i32), ("out", vp), ("ldo", i32),
+                ("nseg", i32), ("k8", vp * 2), ("ldk", i32 * 2), ("vt8", vp * 2), ("ldvt", i32 * 2), ("nk", i32 * 2), ("k_rows", i32 * 2),
+                ("seg_b0", i32 * 2), ("qk_scale_exp", i32), ("v_scale_exp", i32)]
+
+
+class QuantF8Args(C.Structure):
+    _fields_ = [("dtype", i32), ("mode", i32), ("rows", i32), ("cols", i32), ("src", vp), ("lds", i32), ("dst", vp), ("ldd", i32), ("scale", f32)]
+
+
 class SoftmaxArgs(C.Structure):
     _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32)]
 
@@ -79,14 +89,14 @@ STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_
            "idmvton_layernorm_args": LayerNormArgs, "idmvton_groupnorm_args": GroupNormArgs,
            "idmvton_pack_input_args": PackInputArgs, "idmvton_cfg_step_args": CfgStepArgs,
            "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs, "idmvton_softmax_args": SoftmaxArgs,
-           "idmvton_attn_small_args": AttnSmallArgs}
+           "idmvton_attn_small_args": AttnSmallArgs, "idmvton_attn_f8_args": AttnF8Args, "idmvton_quant_f8_args": QuantF8Args}
 
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
            "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles",
            "idmvton_prefetch", "idmvton_attn_small", "idmvton_rccl_unique_id", "idmvton_rccl_comm_init", "idmvton_rccl_bcast_arena",
-           "idmvton_rccl_comm_destroy"]
+           "idmvton_rccl_comm_destroy", "idmvton_attn_f8", "idmvton_quant_f8"]
 
 _lib = None
 
@@ -115,7 +125,7 @@ def lib():
             raise HipLibraryMissing(f"ABI drift: sizeof({name}) is {n} in the library, {C.sizeof(st)} in ffi.py")
     for s in ("idmvton_gemm_conv", "idmvton_attn_fwd", "idmvton_layernorm", "idmvton_groupnorm",
               "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout", "idmvton_vae_sample", "idmvton_softmax_rows",
-              "idmvton_attn_small"):
+              "idmvton_attn_small", "idmvton_attn_f8", "idmvton_quant_f8"):
         getattr(L, s).argtypes = [vp, vp]
         getattr(L, s).restype = C.c_int
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]

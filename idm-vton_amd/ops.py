@@ -211,6 +211,38 @@ def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, 
     return out
 
 
+def quant_f8(src, scale, mode=0, out=None):
+    """16-bit -> e4m3 bytes (torch.uint8) times `scale` (a power of two).  mode 0: src [rows][cols] (row stride src.stride(0)) ->
+    [rows][cols]; mode 1: src = V^T [rows][N] in the 16-bit kernels' key order -> [rows][roundup64(N)] in the fp8 kernel's slot order."""
+    rows, cols = src.shape
+    ldd = cols if mode == 0 else (cols + 63) // 64 * 64
+    if out is None:
+        out = torch.empty((rows, ldd), dtype=torch.uint8, device=src.device)
+    a = ffi.QuantF8Args()
+    a.dtype, a.mode, a.rows, a.cols = _dt(src), mode, rows, cols
+    a.src, a.lds, a.dst, a.ldd, a.scale = _ptr(src), src.stride(0), _ptr(out), out.stride(0), scale
+    _call("idmvton_quant_f8", a, bytes_=float(rows * cols * (src.element_size() + 1)))
+    return out
+
+
+def attention_f8(q8, out, segs, heads, *, qk_scale_exp, v_scale_exp, B, Nq, ldq=None, ldo=None):
+    """fp8 self-attention (csrc/attention_f8.hip).  q8: uint8 [B*Nq][>= heads*64]; segs: list of dict(k8=, vt8=, nk=, ldk=, ldvt=, k_rows=, b0=)."""
+    a = ffi.AttnF8Args()
+    a.out_dtype, a.B, a.heads, a.Nq = _dt(out), B, heads, Nq
+    a.q8, a.ldq = _ptr(q8), (q8.stride(-2) if ldq is None else ldq)
+    a.out, a.ldo = _ptr(out), (out.stride(-2) if ldo is None else ldo)
+    a.nseg = len(segs)
+    fl = 0.0
+    for i, s in enumerate(segs):
+        a.k8[i], a.vt8[i] = _ptr(s["k8"]), _ptr(s["vt8"])
+        a.ldk[i], a.ldvt[i] = s["ldk"], s["ldvt"]
+        a.nk[i], a.k_rows[i], a.seg_b0[i] = s["nk"], s.get("k_rows", 0), s.get("b0", 0)
+        fl += 4.0 * (B - s.get("b0", 0)) * heads * Nq * s["nk"] * 64
+    a.qk_scale_exp, a.v_scale_exp = qk_scale_exp, v_scale_exp
+    _call("idmvton_attn_f8", a, flops=fl, bytes_=float(B * Nq * heads * 64 * (1 + out.element_size())))
+    return out
+
+
 def attention_small(q, k, v, out, heads, d, *, scale, causal=False, B=None, Lq=None, Lk=None, ldq=None, ldk=None, ldv=None, ldo=None):
     """softmax(scale * q k^T [causal]) v, any even head_dim <= 128 (the CLIP towers).  q/out: [B][Lq][>= heads*d], k/v: [B][Lk][...]."""
     a = ffi.AttnSmallArgs()

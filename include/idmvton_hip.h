@@ -21,7 +21,7 @@ extern "C" {
 
 enum { IDMVTON_OK = 0, IDMVTON_E_SHAPE = -1, IDMVTON_E_DTYPE = -2, IDMVTON_E_ALIGN = -3, IDMVTON_E_LAUNCH = -4,
        IDMVTON_E_ARG = -5 };
-enum { IDMVTON_F16 = 0, IDMVTON_BF16 = 1, IDMVTON_F32 = 2 };
+enum { IDMVTON_F16 = 0, IDMVTON_BF16 = 1, IDMVTON_F32 = 2, IDMVTON_F8E4M3 = 3 /* OCP e4m3: idmvton_attn_f8 / idmvton_quant_f8 operands */ };
 
 const char* idmvton_last_error(void);
 int idmvton_abi_version(void);
@@ -146,6 +146,40 @@ typedef struct {
                                     applies it in fp32 in the projection epilogue, same single rounding as an unscaled q) */
 } idmvton_attn_args;
 int idmvton_attn_fwd(const idmvton_attn_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_attn_f8 / idmvton_quant_f8 : the fp8 (OCP e4m3) variant of the self-attention above, on the block-scaled MFMA
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (BASELINE.json configs[4]: "fp16 + fp8 MFMA attention").  SELF semantics only (one softmax over
+ * up to two key segments, closed form for the absent all-zero segment); the cross-attention (93 keys) stays 16-bit.
+ *   q8  : [B][Nq][ldq] bytes, head h at bytes [h*64, h*64+64): e4m3(q * softmax_scale * log2(e) * 2^eq)
+ *   k8_s: [B_s][k_rows_s][ldk_s] bytes: e4m3(k * 2^ek)
+ *   vt8_s: [B_s][heads*64][ldvt_s] bytes: e4m3(v * 2^ev), position 64t + 32u + 16kb + 4g + j of a row holds key 64t + 32kb + 8g + 4u + j
+ *          (the k-slot order of the PV contraction; idmvton_quant_f8 mode 1 builds it from the 16-bit key-ordered V^T), whole 64-key
+ *          tiles per row, zero-filled beyond nk.
+ * qk_scale_exp = -(eq + ek), v_scale_exp = -ev: applied by the MFMA's E8M0 scale operands.  Output in out_dtype (f16 / bf16).
+ * Accuracy: e4m3 carries 3 mantissa bits; on N(0,1) operands the output is within 6e-2 .. 1e-1 max-rel of fp32 SDPA on the unquantised
+ * operands and 2e-2 of fp32 SDPA on the dequantised ones (tests/kernel_checks.py: check_attn_f8; stated tolerances 1.2e-1 / 3e-2).
+ * idmvton_quant_f8: mode 0 rows (dst[r][c] = e4m3(src[r*lds + c] * scale), cols % 16 == 0), mode 1 the V^T re-order above;
+ * saturating at +-448; lds in source elements, ldd in bytes.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t out_dtype; int32_t B, heads, Nq;
+    const void* q8; int32_t ldq;
+    void* out; int32_t ldo;
+    int32_t nseg;
+    const void* k8[2]; int32_t ldk[2];
+    const void* vt8[2]; int32_t ldvt[2];
+    int32_t nk[2]; int32_t k_rows[2]; int32_t seg_b0[2];
+    int32_t qk_scale_exp; int32_t v_scale_exp;
+} idmvton_attn_f8_args;
+int idmvton_attn_f8(const idmvton_attn_f8_args* a, void* stream);
+typedef struct {
+    int32_t dtype; int32_t mode; int32_t rows, cols;
+    const void* src; int32_t lds;
+    void* dst; int32_t ldd;
+    float scale;
+} idmvton_quant_f8_args;
+int idmvton_quant_f8(const idmvton_quant_f8_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * idmvton_attn_small : softmax(scale * q k^T [+ causal mask]) v for the one-off conditioning encoders -- the CLIP text towers

@@ -210,6 +210,101 @@ def check_attn_self(B, heads, N, dtype, dev, n_garm=0, b0=0, scale=1.0, seed=0, 
     return _run_attn(q, out, segs, heads, tune, prescaled, sp, kk, vv, ref)
 
 
+def _e4m3(t):
+    """fp32 -> OCP e4m3 bytes (uint8), saturating, by torch's own conversion (round to nearest even)."""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _e4m3_to_f32(u8):
+    return u8.view(torch.float8_e4m3fn).float()
+
+
+def check_probe_mfma_f8(dev, scaled=False):
+    """One v_mfma_scale_f32_32x32x64_f8f6f4: lane l supplies k-slots 32*(l>>5) .. +31 of row l & 31 (A) / column l & 31 (B), 32 e4m3
+    bytes; result layout = the 32x32 f32 layout of every other MFMA.  scaled: E8M0 scale bytes 124 (A: 2^-3) and 128 (B: 2^1)."""
+    from idm_vton_amd import ops
+    g = torch.Generator().manual_seed(5)
+    A = _e4m3_to_f32(_e4m3(torch.randn(32, 64, generator=g) * 2))           # values exactly representable in e4m3
+    Bm = _e4m3_to_f32(_e4m3(torch.randn(64, 32, generator=g) * 2))          # deliberately not symmetric
+    lane = torch.arange(64)
+    ks = (32 * (lane // 32))[:, None] + torch.arange(32)[None, :]
+    a_frag = _e4m3(A[(lane % 32)[:, None], ks]).contiguous()               # [64 lanes][32 bytes]
+    b_frag = _e4m3(Bm[ks, (lane % 32)[:, None]]).contiguous()
+    c = ops.probe_mfma(3 if scaled else 2, a_frag.to(dev), b_frag.to(dev)).cpu()
+    ref = (A @ Bm) * (0.25 if scaled else 1.0)
+    r = torch.arange(16)
+    rows = (r % 4)[None, :] + 8 * (r // 4)[None, :] + 4 * (lane // 32)[:, None]
+    got = torch.empty(32, 32)
+    got[rows, (lane % 32)[:, None].expand(64, 16)] = c
+    return relerr(got, ref)
+
+
+def check_quant_f8(dtype, dev, seed=0):
+    """idmvton_quant_f8 against torch's float8_e4m3fn conversion (bit-equal bytes): rows mode with a strided source, saturation at
+    +-448, and the V^T re-order (16-bit key order -> fp8 slot order, zero fill of the last partial 64-key tile)."""
+    from idm_vton_amd import ops
+    x = _r(200, 256, dtype=dtype, dev=dev, scale=3.0, seed=seed)
+    x[0, :4] = torch.tensor([1000.0, -1000.0, 448.0, 0.0], dtype=dtype, device=dev)
+    src = x[:, 64:192]                                                       # strided view: lds = 256, cols = 128
+    got = ops.quant_f8(src, 4.0)
+    ok = torch.equal(got.cpu(), _e4m3(src.float().cpu() * 4.0))
+    N = 208                                                                  # 3 full tiles + 16 keys
+    v = _r(5, N, dtype=dtype, dev=dev, scale=1.5, seed=seed + 1)            # plain V^T rows [row][key]
+    vt16 = ops.key_order(v)                                                  # what the 16-bit path stores
+    got2 = ops.quant_f8(vt16, 2.0, mode=1).cpu()
+    pos = torch.arange(256)
+    key = 64 * (pos // 64) + 32 * ((pos // 16) % 2) + 8 * ((pos // 4) % 4) + 4 * ((pos // 32) % 2) + pos % 4
+    vp = torch.zeros(5, 256)
+    vp[:, key < N] = v.float().cpu()[:, key[key < N]]
+    ok = ok and got2.shape == (5, 256) and torch.equal(got2, _e4m3(vp * 2.0))
+    return 0.0 if ok else float("inf")
+
+
+def check_attn_f8(B, heads, N, dtype, dev, n_garm=0, b0=0, seed=0, eq=2, ek=2, ev=2):
+    """fp8 self-attention (idmvton_attn_f8) with the TryonNet attn1 semantics of check_attn_self.  Returns (error against fp32 SDPA on
+    the UNQUANTISED operands, error against fp32 SDPA on the dequantised e4m3 operands): the second isolates the kernel's own
+    arithmetic (P in e4m3, fp32 accumulation) from the quantisation of q, k, v."""
+    from idm_vton_amd import ops
+    Cc = heads * 64
+    q = _r(B, N, Cc, dtype=dtype, dev=dev, seed=seed)
+    k1 = _r(B, N, Cc, dtype=dtype, dev=dev, seed=seed + 1)
+    v1 = _r(B, N, Cc, dtype=dtype, dev=dev, seed=seed + 2)
+    sp = lambda t: t.float().view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+    qs = (q.float() * ops.QSCALE).to(dtype)                                  # what the QKV projection's colscale hands over
+    q8 = ops.quant_f8(qs.view(B * N, Cc), 2.0 ** eq)
+    deq = lambda u8, e: _e4m3_to_f32(u8.cpu()).to(dev) * 2.0 ** -e
+
+    def seg(kx, vx, nk, b0_=0):
+        Bx = kx.shape[0]
+        k8 = ops.quant_f8(kx.view(Bx * nk, Cc), 2.0 ** ek)
+        vt16, ld16 = _key_order_padded(vx, nk)                               # [Bx][C][round16(nk)] in the 16-bit key order
+        vt8 = ops.quant_f8(vt16.view(Bx * Cc, ld16)[:, :ops.round16(nk)], 2.0 ** ev, mode=1)
+        # dequantised operands in plain layout for the second reference
+        kq = deq(k8, ek).view(Bx, nk, Cc)
+        vq = _e4m3_to_f32(_e4m3(vx.float().cpu() * 2.0 ** ev)).to(dev) * 2.0 ** -ev
+        return dict(k8=k8, vt8=vt8, nk=nk, ldk=Cc, ldvt=vt8.shape[1], b0=b0_), kq, vq
+    s1, kq1, vq1 = seg(k1, v1, N)
+    segs = [s1]
+    kk, vv, kkq, vvq = sp(k1), sp(v1), sp(kq1), sp(vq1)
+    if n_garm:
+        Bg = B - b0
+        k2 = _r(Bg, n_garm, Cc, dtype=dtype, dev=dev, seed=seed + 3)
+        v2 = _r(Bg, n_garm, Cc, dtype=dtype, dev=dev, seed=seed + 4)
+        s2, kq2, vq2 = seg(k2, v2, n_garm, b0)
+        segs.append(s2)
+        z = torch.zeros(b0, heads, n_garm, 64, device=dev)
+        kk = torch.cat([kk, torch.cat([z, sp(k2)], dim=0)], dim=2)
+        vv = torch.cat([vv, torch.cat([z, sp(v2)], dim=0)], dim=2)
+        kkq = torch.cat([kkq, torch.cat([z, sp(kq2)], dim=0)], dim=2)
+        vvq = torch.cat([vvq, torch.cat([z, sp(vq2)], dim=0)], dim=2)
+    ref = F.scaled_dot_product_attention(sp(q), kk, vv).transpose(1, 2).reshape(B, N, Cc)
+    qq = sp(deq(q8, eq).view(B, N, Cc)) / ops.QSCALE                         # dequantised q, back in SDPA's units
+    refq = F.scaled_dot_product_attention(qq, kkq, vvq).transpose(1, 2).reshape(B, N, Cc)
+    out = torch.empty(B, N, Cc, dtype=dtype, device=dev)
+    ops.attention_f8(q8, out, segs, heads, qk_scale_exp=-(eq + ek), v_scale_exp=-ev, B=B, Nq=N, ldq=Cc, ldo=Cc)
+    return relerr(out, ref), relerr(out, refq)
+
+
 def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
     """idmvton_attn_args.tune for the ping-pong kernel: 8 waves; deep=0 -> 128 registers, two workgroups per CU (2 LDS stages);
     deep=1 -> one workgroup per CU, `stages` LDS stages, all fragments prefetched, max subtraction on the matrix pipe (needs a
@@ -483,6 +578,10 @@ def all_checks(dev="cuda"):
         tol = TOL[dt]
         add = lambda name, fn, t=tol: out.append((f"{name}[{n}]", fn, t))
         add("probe_mfma", lambda dt=dt: check_probe_mfma(dt, dev), 1e-6 if dt == torch.float16 else 1e-6)
+        if dt == torch.float16:
+            # a wrong operand layout gives O(1) errors; 1.8e-5 measured = the instruction's internal summation of 64 products
+            add("probe_mfma_scale_f8_32x32x64", lambda: check_probe_mfma_f8(dev), 1e-4)
+            add("probe_mfma_scale_f8_32x32x64_scales", lambda: check_probe_mfma_f8(dev, True), 1e-4)
         for hint, tag in ((0, "auto"), ((128 << 16) | 128, "128x128"), ((128 << 16) | 64, "128x64"), ((64 << 16) | 64, "64x64")):
             add(f"linear_768x640x640_{tag}", lambda dt=dt, hint=hint: check_linear(768, 640, 640, dt, dev, tile_hint=hint))
         # LDS-ring variants (tile_hint variant 1): every epilogue / gather mode on every ring tile, incl. M/N tails, K = 1
@@ -562,6 +661,16 @@ def all_checks(dev="cuda"):
             add(f"attn_self_prescaled_2seg_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn, prescaled=True))
             add(f"attn_self_prescaled_ragged_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn, prescaled=True))
             add(f"attn_self_neg_logits_{tag}", lambda dt=dt, tn=tn: check_attn_neg(dt, dev, tune=tn))
+        # fp8 (e4m3) attention on the block-scaled MFMA.  e4m3 has 3 mantissa bits: every q, k, v element carries up to 6 % (3.6 % rms)
+        # relative rounding, and on N(0,1) operands the attention output (an average of ~N values) inherits ~3-4 % rms / 6-10 % max of
+        # its own magnitude.  Measured on MI355X (profiles/r03_fp8_attention_checks.log): 6.2e-2 .. 1.03e-1 against fp32 SDPA on the
+        # unquantised operands, 1.6e-2 .. 2.1e-2 against fp32 SDPA on the DEQUANTISED operands (P's e4m3 rounding + the kernel's own
+        # arithmetic).  Stated tolerances of this variant: 1.2e-1 and 3e-2.
+        for (nm, args) in (("2seg_cfg_N768", (4, 4, 768, 768, 2)), ("ragged_N200", (2, 2, 200, 200, 1)), ("1seg_N1000", (1, 3, 1000, 0, 0)),
+                           ("N3072_h10", (4, 10, 3072, 3072, 2)), ("N16", (2, 1, 16, 16, 1))):
+            add(f"attn_f8_{nm}", lambda dt=dt, a=args: check_attn_f8(a[0], a[1], a[2], dt, dev, n_garm=a[3], b0=a[4])[0], 1.2e-1)
+            add(f"attn_f8_kernel_only_{nm}", lambda dt=dt, a=args: check_attn_f8(a[0], a[1], a[2], dt, dev, n_garm=a[3], b0=a[4])[1], 3e-2)
+        add("quant_f8", lambda dt=dt: check_quant_f8(dt, dev), 0.0)
         add("linear_colscale", lambda dt=dt: check_colscale(dt, dev))
         add("linear_quickgelu", lambda dt=dt: check_quickgelu(dt, dev))
         add("attn_small_text_causal_77_d64", lambda dt=dt: check_attn_small(2, 12, 77, 64, dt, dev, True))
