@@ -104,7 +104,13 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     for i, s in enumerate(segs):
         t = _dev(s.t)
         g = a.seg[i]
-        pitch = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+        # channels per pixel = the stride of the innermost pixel dimension that has more than one entry (torch leaves the strides of
+        # size-1 dimensions arbitrary: a [1][1][1][64] NHWC tensor can report stride(-2) == 1 -- found by the hypothesis sweep)
+        pitch = t.shape[-1]
+        for d in range(t.dim() - 2, -1, -1):
+            if t.shape[d] > 1:
+                pitch = t.stride(d)
+                break
         extent = 1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride()))     # elements reachable from data_ptr
         g.ptr, g.bytes, g.pitch = t.data_ptr(), extent * t.element_size(), pitch
         g.coff, g.len, g.dy, g.dx = s.coff, s.len, s.dy, s.dx

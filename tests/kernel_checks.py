@@ -684,6 +684,9 @@ def all_checks(dev="cuda"):
         add("attn_self_big_logits", lambda dt=dt: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0))
         add("attn_self_N3072_h10", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2))
         add("attn_self_N16", lambda dt=dt: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1))
+        # BASELINE.json configs[3] (1024x1536): the two-segment walks of TryonNet at 6144 + 6144 keys (L1) and 1536 + 1536 (L2)
+        add("attn_self_cfg4_N6144_h10", lambda dt=dt: check_attn_self(2, 10, 6144, dt, dev, n_garm=6144, b0=1))
+        add("attn_self_cfg4_N1536_h20", lambda dt=dt: check_attn_self(2, 20, 1536, dt, dev, n_garm=1536, b0=1))
         add("attn_cross_77_16_N768", lambda dt=dt: check_attn_cross(4, 4, 768, dt, dev))
         add("attn_cross_scale0.5_N200", lambda dt=dt: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5))
         for hint, tag in ((0, "auto"),) + tuple(RING_TILES):

@@ -10,7 +10,16 @@ BAR = {torch.float16: 6e-3, torch.bfloat16: 3e-2}
 
 
 def relerr(x, ref):
-    return ((x.float().cpu() - ref.float()).norm() / ref.float().norm().clamp_min(1e-12)).item()
+    return ((x.float().cpu() - ref.float().cpu()).norm() / ref.float().cpu().norm().clamp_min(1e-12)).item()
+
+
+def maxrel(x, ref):
+    """max|x - ref| / max|ref|: the metric of the kernel checks (a Frobenius norm can hide a wrong token)."""
+    x, ref = x.float().cpu(), ref.float().cpu()
+    return ((x - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+MAXREL_BAR = {torch.float16: 1.2e-2, torch.bfloat16: 8e-2}          # through 3 layers; per-layer values printed with -s
 
 
 def _text(hidden, heads, layers, act, proj, vocab=1000, eos=999, seed=0):
@@ -51,7 +60,7 @@ def test_text_tower_matches_transformers(dtype, case):
     out = hip(ids)
     assert len(out.hidden_states) == len(ref.hidden_states) == layers + 1
     for a, b in zip(out.hidden_states, ref.hidden_states):
-        assert relerr(a, b) < BAR[dtype]
+        assert relerr(a, b) < BAR[dtype] and maxrel(a, b) < MAXREL_BAR[dtype], (relerr(a, b), maxrel(a, b))
     assert relerr(out.last_hidden_state, ref.last_hidden_state) < BAR[dtype]
     assert relerr(out.first, ref[0]) < BAR[dtype]           # what encode_prompt reads as `prompt_embeds[0]` (:601)
     if proj:
@@ -84,7 +93,7 @@ def test_vision_tower_matches_transformers(dtype, case):
     hip = HipCLIPVision(m.state_dict(), m.config, dtype, "cuda")
     out = hip(px)
     for a, b in zip(out.hidden_states, ref.hidden_states):
-        assert relerr(a, b) < BAR[dtype]
+        assert relerr(a, b) < BAR[dtype] and maxrel(a, b) < MAXREL_BAR[dtype], (relerr(a, b), maxrel(a, b))
     assert relerr(out.image_embeds, ref.image_embeds) < BAR[dtype]
     pen = hip(px, penultimate_only=True)
     assert torch.equal(pen.hidden_states[-2], out.hidden_states[-2])
@@ -124,3 +133,37 @@ def test_pipeline_encoders_run_on_hip(tmp_path):
     assert hid.shape == (1, 77, 192) and hid.dtype == torch.float16 and relerr(hid, ref.cpu()) < 6e-3
     assert relerr(pooled, r2[0].cpu()) < 6e-3
     assert pos.shape == neg.shape == (1, 257, 128)
+
+
+@pytest.mark.parametrize("tower", ["vision_H_32_layers", "text_bigG_32_layers", "text_L_12_layers"])
+def test_full_depth_towers_match_transformers(tower):
+    """The REAL depths (ckpt/image_encoder/config.json: CLIP ViT-H/14, 32 layers, 16 heads x 80, 257 tokens; CLIP-bigG text 32 layers,
+    CLIP-L text 12 layers): the pipeline reads hidden_states[-2] (tryon_pipeline.py:468,633-645), i.e. 31 / 31 / 11 chained pre-LN
+    layers of 16-bit storage.  Reference: the transformers module itself in fp32 (executed by torch on the GPU).  Default
+    (std 0.02) initialisation; both metrics, fp16 and bf16."""
+    from idm_vton_amd.clip import HipCLIPText, HipCLIPVision
+    # measured on MI355X (round 3): fp16 1.1e-3 .. 1.7e-3 Frobenius / 1.6e-3 .. 4.2e-3 max-rel; bf16 0.9e-2 .. 1.4e-2 / 1.3e-2 .. 3.4e-2
+    bars = {torch.float16: (4e-3, 1e-2), torch.bfloat16: (3e-2, 8e-2)}                  # (Frobenius, max-rel) after 31 layers: one 16-bit rounding x sqrt(depth)
+    if tower.startswith("vision"):
+        from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+        torch.manual_seed(11)
+        m = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16,
+                                                           image_size=224, patch_size=14, projection_dim=1024, hidden_act="gelu")).eval()
+        x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+        x[1] = 0
+        cls = HipCLIPVision
+    else:
+        hidden, heads, layers, act, proj = (1280, 20, 32, "gelu", 1280) if "bigG" in tower else (768, 12, 12, "quick_gelu", 0)
+        m = _text(hidden, heads, layers, act, proj)
+        x = _ids(2, 77, 1000, 999, 1)
+        cls = HipCLIPText
+    with torch.no_grad():
+        ref = m.cuda()(x.cuda(), output_hidden_states=True)
+    m.cpu()
+    for dtype in (torch.float16, torch.bfloat16):
+        hip = cls(m.state_dict(), m.config, dtype, "cuda")
+        out = hip(x)
+        fro, mx = relerr(out.hidden_states[-2], ref.hidden_states[-2]), maxrel(out.hidden_states[-2], ref.hidden_states[-2])
+        print(f"{tower} {dtype}: hidden_states[-2] frobenius {fro:.3e} max-rel {mx:.3e}; last {relerr(out.hidden_states[-1], ref.hidden_states[-1]):.3e}")
+        assert fro < bars[dtype][0] and mx < bars[dtype][1], (tower, dtype, fro, mx)
+        del hip
