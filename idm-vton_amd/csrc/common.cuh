@@ -83,6 +83,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Wave-wide sum on the DPP path (no LDS crossbar: __shfl_xor is ds_bpermute_b32, ~100 cycles a step): quad butterflies, row mirrors,
+// then the four 16-lane row totals through readlane.  The result is wave-uniform and the summation ORDER is fixed (deterministic).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xf, 0xf, false));   // row_mirror: every lane = its row's total
+    const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+    const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+    const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+    const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // Exchange between the two 32-lane halves of a wave without the LDS crossbar (v_permlane32_swap: lanes 32-63 of the first
 // operand swap with lanes 0-31 of the second): max / sum of a value with its partner lane (lane ^ 32).
 __device__ __forceinline__ float xhalf_max(float v) {

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
     }
-    const float mean = wave_sum(s) / (float)a.C;
+    const float mean = wave_sum_dpp(s) / (float)a.C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_
             for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+    const float rstd = rsqrtf(wave_sum_dpp(q) / (float)a.C + a.eps);
     const T* gamma = (const T*)a.gamma;
     const T* beta = (const T*)a.beta;
     T* y = (T*)a.y + (size_t)row * a.ldy;
