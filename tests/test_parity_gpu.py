@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 # `image` = the VAE decode of latents that already differ by `latents`: the random-init test VAE (std 0.05 weights, 4 levels) roughly
 # doubles a relative latent difference on top of its own ~2.5e-3 / 2e-2 storage rounding (tests/test_fullsize_parity_gpu.py: decode)
 TOL = {torch.float16: dict(stage=4e-3, latents=5e-3, image=1.5e-2),
-       torch.bfloat16: dict(stage=3e-2, latents=4e-2, image=6e-2)}
+       torch.bfloat16: dict(stage=3e-2, latents=4e-2, image=1e-1)}
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
