@@ -255,6 +255,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         }
         return;
     }
+    // (128x128-per-wave tiles, NI * MI = 16, exist only with the 16-byte epilogue: this nest no longer unrolls fully there and the
+    //  runtime-indexed accumulators would move to scratch -- 1088 bytes per lane measured; launch_gemm falls back to the 8-wave tile)
+    if constexpr (NI * MI <= 8)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * SM + mi * 32 + l31;
@@ -620,8 +623,12 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
         tn = rem / gsz; tm = first + (rem - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true>(p, smem, m0, n0);   // block-uniform
-    else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false>(p, smem, m0, n0);
+    if constexpr (BN == 256 && BM == 256 && WN * WM == 4) {    // 128x128 per wave: never launched with a transposed part (launch_gemm)
+        gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, true, false>(p, smem, m0, n0);
+    } else {
+        if (p.vt != nullptr && n0 >= p.vt_n0) gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, true>(p, smem, m0, n0);   // block-uniform
+        else gemm_body<T, BN, BM, WN, WM, ST, V1, LIN, OCC == 1 || PFX, false>(p, smem, m0, n0);
+    }
 }
 
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
@@ -656,6 +663,10 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 3, true, 2, true>(p, lin, st);
         else if (bn == 64 && bm == 64) launch_cfg<T, 64, 64, 2, 2, 4, true, 2, true>(p, lin, st);
         else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v2 tile %dx%d", bn, bm);
+    } else if (variant == 3) {                           // 256x256, 4 waves x (128x128): one wave per SIMD, accumulators in AGPRs, a third fewer
+        if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 3 is the 256x256 tile");   // LDS fragment reads
+        if (p.wide && !p.vt) launch_cfg<T, 256, 256, 2, 2, 2, true, 1>(p, lin, st);
+        else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue or a V^T part: the 8-wave tile
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;

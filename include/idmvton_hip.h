@@ -77,7 +77,8 @@ typedef struct {
     void* vt; int32_t vt_n0; int32_t vt_tokens;
     int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
-                                    variant 1 with register-prefetched fragments on every tile.  Bit 15
+                                    variant 1 with register-prefetched fragments on every tile; variant 3 = 256x256 as 4 waves of 128x128 (AGPR
+                                    accumulators, one wave per SIMD).  Bit 15
                                     (0x8000) forces the 8-byte epilogue (measurement only; default: 16-byte accesses when every
                                     epilogue operand is 16-byte aligned with strides / N multiples of 8).
                                     Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */

@@ -565,7 +565,7 @@ def _hint(variant, bn, bm):
     return (variant << 28) | (bn << 16) | bm
 
 
-RING_TILES = ((_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
+RING_TILES = ((_hint(3, 256, 256), "q256x256"), (_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))
 

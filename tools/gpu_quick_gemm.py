@@ -1,4 +1,4 @@
-"""Quick A/B of GEMM tile variants on the real config-2 shapes (cold caches, HIP events, median of 7)."""
+"""Quick A/B of GEMM tile variants on the real config-2 shapes (warm: 20 back-to-back launches; cold: behind a cache flush, median of 7)."""
 import os
 import sys
 
@@ -20,7 +20,7 @@ def main():
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(dt)
     flush = torch.empty(640 << 20, dtype=torch.uint8, device=dev)
 
-    def timed(fn):
+    def cold(fn):
         fn(); fn()
         ts = []
         for _ in range(7):
@@ -30,25 +30,36 @@ def main():
             ts.append(e0.elapsed_time(e1) * 1e3)
         return sorted(ts)[3]
 
+    def warm(fn, n=20):
+        fn(); fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
     cases = []
-    x, w, b = r(3072, 1280), r(10240, 1280), r(10240)
-    wi, bi = interleave_geglu(w, b)
-    cases.append(("geglu 3072x10240x1280", 2 * 3072 * 10240 * 1280, lambda h: ops.linear(x, wi, bias=bi, geglu=True, tile_hint=h),
-                  [("r256x256", hint(1, 256, 256)), ("p256x256", hint(2, 256, 256)), ("r128x256", hint(1, 128, 256)), ("p128x256", hint(2, 128, 256))]))
-    x2, w2, rs2 = r(3072, 1280), r(1280, 1280), r(3072, 1280)
-    cases.append(("proj 3072x1280x1280", 2 * 3072 * 1280 * 1280, lambda h: ops.linear(x2, w2, res=rs2, tile_hint=h),
-                  [("r128x128", hint(1, 128, 128)), ("r128x64", hint(1, 128, 64)), ("p128x64", hint(2, 128, 64)), ("p64x64", hint(2, 64, 64))]))
-    x3, rs3 = r(1536, 1280), r(1536, 1280)
-    cases.append(("proj 1536x1280x1280", 2 * 1536 * 1280 * 1280, lambda h: ops.linear(x3, w2, res=rs3, tile_hint=h),
-                  [("r128x64", hint(1, 128, 64)), ("p128x64", hint(2, 128, 64)), ("r64x64", hint(1, 64, 64)), ("p64x64", hint(2, 64, 64))]))
-    x4, w4 = r(3072, 5120), r(1280, 5120)
-    cases.append(("ff2 3072x1280x5120", 2 * 3072 * 1280 * 5120, lambda h: ops.linear(x4, w4, res=rs2, tile_hint=h),
-                  [("r128x128", hint(1, 128, 128)), ("p128x64", hint(2, 128, 64)), ("p128x256", hint(2, 128, 256))]))
-    w5 = r(3840, 1280)
-    cases.append(("qkv 3072x3840x1280", 2 * 3072 * 3840 * 1280, lambda h: ops.linear(x2, w5, tile_hint=h),
-                  [("r128x128", hint(1, 128, 128)), ("r128x256", hint(1, 128, 256)), ("p128x256", hint(2, 128, 256)), ("p256x256", hint(2, 256, 256))]))
+    big = [("q256x256", hint(3, 256, 256)), ("r256x256", hint(1, 256, 256)), ("p256x256", hint(2, 256, 256)), ("r128x256", hint(1, 128, 256))]
+    for (M, C, tag) in ((3072, 1280, "TryonNet L2"), (12288, 640, "TryonNet L1"), (9216, 1280, "GarmentNet L2 x6"), (36864, 640, "GarmentNet L1 x6")):
+        x, w, b = r(M, C), r(8 * C, C), r(8 * C)
+        wi, bi = interleave_geglu(w, b)
+        cases.append((f"geglu {M}x{8 * C}x{C} ({tag})", 2 * M * 8 * C * C, lambda h, x=x, wi=wi, bi=bi: ops.linear(x, wi, bias=bi, geglu=True, tile_hint=h), big))
+        x4, w4, rs = r(M, 4 * C), r(C, 4 * C), r(M, C)
+        cases.append((f"ff2 {M}x{C}x{4 * C} ({tag})", 2 * M * C * 4 * C, lambda h, x4=x4, w4=w4, rs=rs: ops.linear(x4, w4, res=rs, tile_hint=h),
+                      big + [("r128x128", hint(1, 128, 128))]))
+    x2, w5 = r(3072, 1280), r(3840, 1280)
+    cases.append(("qkv-like plain 3072x3840x1280", 2 * 3072 * 3840 * 1280, lambda h: ops.linear(x2, w5, tile_hint=h), big))
     for name, fl, fn, vs in cases:
-        print(name, " ".join(f"{tag}={(t := timed(lambda: fn(h))):.1f}us/{fl / t / 1e6:.0f}TF" for tag, h in vs), flush=True)
+        out = []
+        for tag, h in vs:
+            try:
+                tc, tw = cold(lambda: fn(h)), warm(lambda: fn(h))
+                out.append(f"{tag}={tc:.1f}/{tw:.1f}us ({fl / tw / 1e6:.0f}TF)")
+            except Exception as e:
+                out.append(f"{tag}=ERR")
+        print(name, " ".join(out), flush=True)
 
 
 if __name__ == "__main__":
