@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_a
     }
 }
 
-// one wave per (batch, group): block partials summed in a fixed order -> stats[(b*groups + g)*2 + {0, 1}]
-__global__ __launch_bounds__(64) void gn_finalize_kernel(double* stats, int bg, int nblk) {
+// one wave per (batch, group): block partials summed in a fixed order -> (mean, rstd) as two floats in stats[(b*groups + g)*2]
+// (the double-precision division / square root happen ONCE per group here instead of 8 times per thread of the apply kernel)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(double* stats, int bg, int nblk, double cnt, double eps) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const double* part = stats + (size_t)2 * bg + (size_t)i * nblk * 2;
     double ds = 0.0, dq = 0.0;
@@ -177,7 +178,14 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(double* stats, int bg, 
     for (; k < nblk; k += 64) { ds += part[2 * k]; dq += part[2 * k + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
-    if (lane == 0) { stats[2 * i] = ds; stats[2 * i + 1] = dq; }
+    if (lane == 0) {
+        const double mean = ds / cnt;
+        double var = dq / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        float* o = (float*)(stats + 2 * i);
+        o[0] = (float)mean;
+        o[1] = (float)(1.0 / sqrt(var + eps));
+    }
 }
 
 template <typename T>
@@ -190,7 +198,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_a
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, a.HW);
     const int cpg = a.C / a.groups;
-    const double cnt = (double)cpg * (double)a.HW;
     const T* gamma = (const T*)a.gamma;
     const T* beta = (const T*)a.beta;
     for (int cb = chunk; cb < nchunk; cb += 256) {
@@ -202,12 +209,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_a
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c0 + j, g = c / cpg;
-            const double mean = a.stats[((size_t)b * a.groups + g) * 2 + 0] / cnt;
-            double var = a.stats[((size_t)b * a.groups + g) * 2 + 1] / cnt - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-            sc[j] = rstd * (float)gamma[c];
-            sh[j] = (float)beta[c] - (float)mean * sc[j];
+            const float2 mr = *(const float2*)(a.stats + ((size_t)b * a.groups + g) * 2);      // (mean, rstd) from gn_finalize_kernel
+            sc[j] = mr.y * (float)gamma[c];
+            sh[j] = (float)beta[c] - mr.x * sc[j];
         }
         if (psub < tpp) {
             T* dst = (T*)a.y;
@@ -260,7 +264,8 @@ static int launch_gn(const idmvton_groupnorm_args& a, hipStream_t st) {
     gn_geometry(a, nblk, ppb);
     const dim3 grid(nblk, a.B), block(256);
     hipLaunchKernelGGL((gn_stats_kernel<T>), grid, block, 0, st, a, ppb, nblk);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B * a.groups), dim3(64), 0, st, a.stats, a.B * a.groups, nblk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B * a.groups), dim3(64), 0, st, a.stats, a.B * a.groups, nblk,
+                       (double)(a.C / a.groups) * (double)a.HW, (double)a.eps);
     hipLaunchKernelGGL((gn_apply_kernel<T>), grid, block, 0, st, a, ppb);
     CHECK_LAUNCH("groupnorm");
     return IDMVTON_OK;
