@@ -15,6 +15,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_
     const int nchunk = a.C >> 3;
     const T* x = (const T*)a.x + (size_t)row * a.ldx;
     const float* xf = (const float*)a.x + (size_t)row * a.ldx;      // X32: the fp32 residual stream
+    const T* gamma = (const T*)a.gamma;
+    const T* beta = (const T*)a.beta;
+    v8 gm[NCH], bt_[NCH];                                // gamma / beta issued with the row loads: their L2 latency used to sit behind
+#pragma unroll                                           // the two reductions, in front of the stores (this kernel is one latency chain per wave)
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) { gm[i] = *(const v8*)(gamma + c * 8); bt_[i] = *(const v8*)(beta + c * 8); }
+    }
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
@@ -48,19 +56,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_
         }
     }
     const float rstd = rsqrtf(wave_sum_dpp(q) / (float)a.C + a.eps);
-    const T* gamma = (const T*)a.gamma;
-    const T* beta = (const T*)a.beta;
     T* y = (T*)a.y + (size_t)row * a.ldy;
     T* y2 = a.y2 ? (T*)a.y2 + (size_t)row * a.ldy2 : nullptr;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const v8 g = *(const v8*)(gamma + c * 8);
-            const v8 bt = *(const v8*)(beta + c * 8);
             v8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (T)((v[i][j] - mean) * rstd * (float)g[j] + (float)bt[j]);
+            for (int j = 0; j < 8; ++j) o[j] = (T)((v[i][j] - mean) * rstd * (float)gm[i][j] + (float)bt_[i][j]);
             *(v8*)(y + c * 8) = o;
             if (y2) *(v8*)(y2 + c * 8) = o;
         }
