@@ -53,8 +53,9 @@ def _ref_script(name):
     return None
 
 
-def _launch(script, args, cwd, timeout=900):
+def _launch(script, args, cwd, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "IDMVTON_DROPIN_RECORD")}
+    env.update(extra_env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_launcher.py"), script] + args, capture_output=True, text=True,
                           env=env, cwd=cwd, timeout=timeout)
 
@@ -76,10 +77,12 @@ def test_unmodified_inference_py_produces_pixels_on_the_mi355x(tmp_path):
         assert a.shape == (256, 256, 3) and a.std() > 1.0
 
 
+@pytest.mark.parametrize("fp8", [False, True], ids=["fp16", "fp16_fp8_attention"])
 @pytest.mark.skipif(_ref_script("inference_dc.py") is None, reason="no copy of the reference's inference_dc.py on this box")
-def test_unmodified_inference_dc_py_produces_pixels_on_the_mi355x(tmp_path):
-    """SURVEY.md 8f-2 / BASELINE.json configs[4]'s data path: DresscodeTestDataset + get_agnostic (inference_dc.py:96-352), the
-    hub id "yisol/IDM-VTON-DC" (:391) resolved relative to the run directory, upper_body."""
+def test_unmodified_inference_dc_py_produces_pixels_on_the_mi355x(tmp_path, fp8):
+    """SURVEY.md 8f-2 / BASELINE.json configs[4]: DresscodeTestDataset + get_agnostic (inference_dc.py:96-352), the hub id
+    "yisol/IDM-VTON-DC" (:391) resolved relative to the run directory, upper_body; the second case is configs[4] as named --
+    "DressCode upper_body ... fp16 + fp8 MFMA attention" -- selected by IDMVTON_ATTN_FP8=1 with the script untouched."""
     from tests.test_dropin_cpu import _make_assets
     from PIL import Image
     ck, _ = _make_assets(tmp_path, n=1)
@@ -94,7 +97,7 @@ def test_unmodified_inference_dc_py_produces_pixels_on_the_mi355x(tmp_path):
     out = str(tmp_path / "out")
     r = _launch(_ref_script("inference_dc.py"), ["--pretrained_model_name_or_path", ck, "--data_dir", dd, "--width", "256", "--height", "256",
                                                  "--num_inference_steps", "4", "--output_dir", out, "--test_batch_size", "2",
-                                                 "--category", "upper_body"], str(run))
+                                                 "--category", "upper_body"], str(run), extra_env={"IDMVTON_ATTN_FP8": "1"} if fp8 else None)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
     assert sorted(os.listdir(out)) == ["000000_0.jpg", "000001_0.jpg"]
     for n in os.listdir(out):
