@@ -34,10 +34,15 @@ runs the reference's OWN first-party code with a test-only stand-in for the thir
     The third-party LAYERS those files call (diffusers Attention, ResnetBlock2D, Down/Upsample2D, GEGLU, Timesteps,
     TimestepEmbedding) are supplied by tests/compat/refstub, written from that release's published semantics -- their
     source is not under /root/reference, so for them the pin is to an independent restatement, not to diffusers itself.
-  * UNPINNED ("parity unpinned"): oracle/vae.py (diffusers AutoencoderKL) and oracle/scheduler.py (diffusers DDPM / DDIM step):
-    pure third-party arithmetic whose source is not under /root/reference -- restated from SURVEY.md Appendix B, self-checked by
-    closed-form schedule values (alphas_cumprod[0] = 0.99915, the DDIM / DDPM identities of tests/test_oracle.py), not by outputs
-    of diffusers itself.
+  * PINNED AT BLOCK LEVEL (round 3): oracle/vae.py -- MidBlock (with its attention), DownEncoderBlock2D, UpDecoderBlock2D against
+    the reference-held verbatim diffusers-0.25 classes (/root/reference/src/unet_block_hacked_tryon.py:505-627, :1292-1349,
+    :2511-2568, attention through /root/reference/ip_adapter/attention_processor.py:213-276), seeded weights, fixture
+    `vae_*` tensors in tests/golden/reference_unet_tiny.safetensors (tests/test_oracle.py::
+    test_oracle_vae_blocks_match_reference_code_golden).  What stays UNPINNED ("parity unpinned") is only the Encoder / Decoder /
+    AutoencoderKL WIRING around those blocks (conv_in/out, block order, quant convs, scaling factor) and oracle/scheduler.py
+    (diffusers DDPM / DDIM step): third-party code whose source is not under /root/reference -- restated from SURVEY.md Appendix B,
+    self-checked by closed-form schedule values (alphas_cumprod[0] = 0.99915, the DDIM / DDPM identities of tests/test_oracle.py),
+    shape / parameter-count identities and the pipeline-level pin above (which exercises the wiring through the adapters).
 
 Every function cites the reference file:line it follows.
 """

@@ -3,7 +3,9 @@
 The reference calls diffusers' AutoencoderKL (src/tryon_pipeline.py:924,1646,1876); its source is not under
 /root/reference.  Block structure follows the verbatim diffusers-0.25 copies the reference carries in
 src/unet_block_hacked_tryon.py (`DownEncoderBlock2D :1292-1349`, `UpDecoderBlock2D :2511-2568`,
-`UNetMidBlock2D :505-627`) and SURVEY.md A.3 / B.7.  Parity unpinned (see oracle/__init__.py).
+`UNetMidBlock2D :505-627`) and SURVEY.md A.3 / B.7.  The three block types are pinned to those reference-held classes
+(tests/test_oracle.py::test_oracle_vae_blocks_match_reference_code_golden); the Encoder / Decoder wiring around them is
+"parity unpinned" (see oracle/__init__.py).
 """
 from dataclasses import dataclass
 from typing import Tuple
