@@ -9,7 +9,7 @@ int idmvton_set_error(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* idmvton_last_error(void) { return g_err; }
-extern "C" int idmvton_abi_version(void) { return 4; }   // 4: gemm io_flags (fp32 residual stream), layernorm x_f32, attn ldvt % 16
+extern "C" int idmvton_abi_version(void) { return 5; }   // 5: LayerNorm fold with per-row final statistics (rowstats_final / rowstats_counter), ln_parts / ln_eps gone
 
 // ---- TryonNet input: cat([latents]*2 | mask | masked | pose) -> NHWC[cpad] (tryon_pipeline.py:1769,1777) ----
 template <typename T>

@@ -37,8 +37,9 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
-    float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group)
-    const float* ln_rowstats; const float* ln_colvec; int ln_parts; float ln_eps;   // consumer: LayerNorm folded into this GEMM
+    float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
+    float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
+    const float* ln_rowstats; const float* ln_colvec;    // consumer: LayerNorm folded into this GEMM (ln_rowstats = a producer's rs_final)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -249,7 +250,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 if (p.rowstats_out) {                      // block-uniform; N % 32 == 0, so the whole 32-column group is inside N
                     rs1 = xhalf_sum(rs1); rs2 = xhalf_sum(rs2);    // lanes l and l + 32 hold the two column halves of the same row
                     const int grp32 = (n0 + wn * SN + ni * 32) >> 5;
-                    if (u == 0 && grp32 < p.rs_parts) *(float2*)(p.rowstats_out + ((size_t)m * p.rs_parts + grp32) * 2) = make_float2(rs1, rs2);
+                    // one aligned 8-byte agent-scope store (write-through): read back by another CU's workgroup inside this launch
+                    if (u == 0 && grp32 < p.rs_parts) st_agent_f2(p.rowstats_out + ((size_t)m * p.rs_parts + grp32) * 2, rs1, rs2);
                 }
             }
         }
@@ -512,6 +514,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     };
 
+    // folded LayerNorm: this thread's row of the tile, (rstd, -rstd*mean) as its producer's last tile left it; one 8-byte load in
+    // flight under the whole main loop (the per-tile fold of 20-40 partials this replaces cost 5-17 us per consumer launch)
+    static_assert(NW * 64 >= BM, "one thread per tile row");
+    float2 ln_ab = make_float2(1.f, 0.f);
+    if (p.ln_rowstats && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) ln_ab = ((const float2*)p.ln_rowstats)[m0 + threadIdx.x];
+
     const int nt = p.Ktot >> 6;
     if constexpr (!V1) {
         issue(0, 0);
@@ -541,34 +549,50 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 
     const float* fin = nullptr;                          // LDS: (rstd, -rstd*mean) of this tile's rows, nullptr = no folded LayerNorm
     if (p.ln_rowstats) {                                 // block-uniform: LayerNorm of the activation operand folded into this GEMM
-        // fold the per-32-column (sum, sum of squares) partials of this tile's BM rows -> (rstd, -rstd*mean) in LDS, fixed order
+        __syncthreads();                                 // every wave is done with the last LDS stage
+        if ((int)threadIdx.x < BM) ((float2*)smem)[threadIdx.x] = ln_ab;
+        __syncthreads();
+        fin = (const float*)smem;
+    }
+    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, fin);
+
+    if (p.rs_counter) {                                  // block-uniform: producer of LayerNorm row statistics
+        // Inter-workgroup hand-off inside the launch (guide G16, "payload write-through + counter"): the partials left as agent-scope
+        // stores; every wave drains them, one lane counts this tile on its row tile; the tile that arrives last reads the row tile's
+        // partials back with agent-scope loads (never plain ones: this CU's L1 / this XCD's L2 may hold older lines of the same
+        // addresses), folds them in a fixed order and leaves the counter zero for the next launch.
         constexpr int NT = NW * 64, TPR = NT / BM;       // threads per row
         static_assert(TPR >= 1 && TPR * BM == NT, "threads per row");
-        __syncthreads();                                 // every wave is done with the last LDS stage
-        float* scr = (float*)smem;                       // [TPR][BM][2] partial folds, then [BM][2] final at fin_
-        float* fin_ = scr + TPR * BM * 2;
-        fin = fin_;
-        {
-            const int tid = threadIdx.x, r = tid % BM, part = tid / BM;
-            const int P = p.ln_parts, chunk = (P + TPR - 1) / TPR;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                 // also: every wave is done with `fin`
+        unsigned* flag = (unsigned*)smem;
+        const int tid = threadIdx.x;
+        uint32_t* cnt = p.rs_counter + m0 / BM;
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old + 1u == (unsigned)p.tiles_n ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flag) {
+            float* scr = (float*)(smem + 16);            // [TPR][BM][2] partial folds
+            const int r = tid % BM, part = tid / BM;
+            const int P = p.rs_parts, chunk = (P + TPR - 1) / TPR;
             const int m = m0 + r;
             float s1 = 0.f, s2 = 0.f;
             if (m < p.M) {
-                // eight partials in flight per batch: a rolled `load; add` loop is one dependent L2 round trip per partial (20-40 of
-                // them, 10-20 us per tile); the summation order is unchanged
-                const float2* rs = (const float2*)p.ln_rowstats + (size_t)m * P;
+                const float* rs = p.rowstats_out + (size_t)m * P * 2;
                 const int j1 = (part + 1) * chunk < P ? (part + 1) * chunk : P;
-                for (int j = part * chunk; j < j1; j += 8) {
+                for (int j = part * chunk; j < j1; j += 8) {   // eight loads in flight per batch, summed in index order
                     float2 t[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) t[q] = j + q < j1 ? rs[j + q] : make_float2(0.f, 0.f);
+                    for (int q = 0; q < 8; ++q) t[q] = j + q < j1 ? ld_agent_f2(rs + (j + q) * 2) : make_float2(0.f, 0.f);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { s1 += t[q].x; s2 += t[q].y; }
                 }
             }
             scr[(part * BM + r) * 2] = s1; scr[(part * BM + r) * 2 + 1] = s2;
             __syncthreads();
-            if (tid < BM) {
+            if (tid < BM && m0 + tid < p.M) {
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll
                 for (int q = 0; q < TPR; ++q) { a1 += scr[(q * BM + tid) * 2]; a2 += scr[(q * BM + tid) * 2 + 1]; }
@@ -576,13 +600,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
                 const float mean = a1 * invc;
                 float var = a2 * invc - mean * mean;
                 var = var > 0.f ? var : 0.f;
-                const float rstd = rsqrtf(var + p.ln_eps);
-                fin_[tid * 2] = rstd; fin_[tid * 2 + 1] = -rstd * mean;
+                const float rstd = rsqrtf(var + p.rs_eps);
+                *(float2*)(p.rs_final + (size_t)(m0 + tid) * 2) = make_float2(rstd, -rstd * mean);   // read by the NEXT launch: plain store
             }
-            __syncthreads();
+            if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, fin);
 }
 
 // Tile configurations.  id = the `variant` field of tile_hint (bits 28..31); BN/BM in bits 16..27 / 0..15.
@@ -733,15 +756,18 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
     if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
     p.rowstats_out = a->rowstats_out; p.rs_parts = a->N / 32;
-    p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec; p.ln_parts = a->ln_parts; p.ln_eps = a->ln_eps;
-    if (a->rowstats_out) {
-        CHECK_ARG(a->N % 32 == 0 && !geglu && !a->vt && a->out && p.wide && !(a->io_flags & IDMVTON_IO_OUT_F32) && ((uintptr_t)a->rowstats_out & 7) == 0,
+    p.rs_final = a->rowstats_final; p.rs_counter = a->rowstats_counter; p.rs_eps = a->rowstats_eps;
+    p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec;
+    if (a->rowstats_out || a->rowstats_final || a->rowstats_counter) {
+        CHECK_ARG(a->rowstats_out && a->rowstats_final && a->rowstats_counter && a->rowstats_eps > 0.f, IDMVTON_E_ARG,
+                  "gemm_conv: rowstats_out, rowstats_final, rowstats_counter and rowstats_eps > 0 come together");
+        CHECK_ARG(a->N % 32 == 0 && !geglu && !a->vt && a->out && p.wide && !(a->io_flags & IDMVTON_IO_OUT_F32) &&
+                  ((uintptr_t)a->rowstats_out & 7) == 0 && ((uintptr_t)a->rowstats_final & 7) == 0 && ((uintptr_t)a->rowstats_counter & 3) == 0,
                   IDMVTON_E_ARG, "gemm_conv: rowstats_out needs N %% 32 == 0 (N=%d), the plain 16-byte epilogue, a 16-bit out", a->N);
     }
     if (a->ln_rowstats) {
-        CHECK_ARG(a->ln_colvec && a->ln_parts > 0 && a->ln_parts * 32 == a->seg[0].len && a->nseg == 1 && a->ln_eps > 0.f &&
-                  ((uintptr_t)a->ln_rowstats & 7) == 0 && ((uintptr_t)a->ln_colvec & 15) == 0,
-                  IDMVTON_E_ARG, "gemm_conv: folded LayerNorm needs one K segment of ln_parts*32 = K columns (parts=%d, K=%d) and ln_colvec", a->ln_parts, a->Ktot);
+        CHECK_ARG(a->ln_colvec && a->nseg == 1 && ((uintptr_t)a->ln_rowstats & 7) == 0 && ((uintptr_t)a->ln_colvec & 15) == 0,
+                  IDMVTON_E_ARG, "gemm_conv: folded LayerNorm needs one K segment (nseg=%d) and ln_colvec", a->nseg);
     } else CHECK_ARG(!a->ln_colvec, IDMVTON_E_ARG, "gemm_conv: ln_colvec without ln_rowstats");
     p.res32 = (a->io_flags & IDMVTON_IO_RES_F32) ? 1 : 0;
     p.out32 = (a->io_flags & IDMVTON_IO_OUT_F32) ? 1 : 0;

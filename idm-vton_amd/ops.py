@@ -91,9 +91,9 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
               vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, rowstats_out=None, ln=None):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
     fp32 residual stream: a float32 `res` is read as fp32; out_f32=True (or a float32 `out`) writes fp32 (io_flags).
-    LayerNorm folded into the GEMMs around it: rowstats_out = fp32 [M][N/32][2] written by the PRODUCER of a hidden state (sum, sum of
-    squares per 32-column group of the stored values); ln = (rowstats, colvec fp32 [2][N] {s, c}, eps) on the CONSUMER, whose weights
-    carry gamma (see ln_fold_weights).
+    LayerNorm folded into the GEMMs around it: rowstats_out = a RowStats on the PRODUCER of a hidden state (its tiles emit (sum, sum of
+    squares) per 32-column group of the stored values, the last tile to finish a row tile folds them to (rstd, -rstd*mean) per row);
+    ln = (that RowStats, colvec fp32 [2][N] {s, c}) on the CONSUMER, whose weights carry gamma (see ln_fold_weights).
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
     kernel's key order (see key_order()), False as a plain transpose."""
     a = ffi.GemmConvArgs()
@@ -132,10 +132,16 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.colscale_n, a.colscale = colscale_n, colscale
-    a.rowstats_out = _ptr(rowstats_out)
+    if rowstats_out is not None:
+        rs = rowstats_out
+        if rs.M < M or rs.C != N:
+            raise ValueError(f"RowStats({rs.M}, {rs.C}) on a producer of [{M}][{N}]")
+        a.rowstats_out, a.rowstats_final, a.rowstats_counter, a.rowstats_eps = _ptr(rs.partials), _ptr(rs.final), _ptr(rs.counter), rs.eps
     if ln is not None:
-        rs, colvec, eps = ln
-        a.ln_rowstats, a.ln_colvec, a.ln_parts, a.ln_eps = _ptr(rs), _ptr(colvec), Ktot // 32, eps
+        rs, colvec = ln
+        if rs.M < M or rs.C != Ktot:
+            raise ValueError(f"RowStats({rs.M}, {rs.C}) on a consumer of [{M}][{Ktot}]")
+        a.ln_rowstats, a.ln_colvec = _ptr(rs.final), _ptr(colvec)
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))
@@ -148,6 +154,20 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     obytes = (M * (N // 2 if geglu else N)) * (out.element_size() if out is not None else esz) + (M * N * res.element_size() if res is not None else 0)
     _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
+
+
+class RowStats:
+    """Scratch of one LayerNorm fold (include/idmvton_hip.h, rowstats_*): fp32 partials [M][C/32][2], final [M][2] = (rstd, -rstd*mean),
+    one uint32 arrival counter per 64 rows -- zero here, left zero by every launch.  One object serves every producer -> consumer pair
+    of its shape that runs on ONE stream in order; launches that may overlap need their own."""
+
+    def __init__(self, M, C, device, eps=1e-5):
+        if C % 32:
+            raise ValueError("RowStats: C %% 32 != 0 (C=%d)" % C)
+        self.M, self.C, self.eps = M, C, float(eps)
+        self.partials = torch.empty(M * (C // 32) * 2, dtype=torch.float32, device=device)
+        self.final = torch.empty(M * 2, dtype=torch.float32, device=device)
+        self.counter = torch.zeros((M + 63) // 64, dtype=torch.int32, device=device)
 
 
 def ln_fold_weights(w, gamma, beta):

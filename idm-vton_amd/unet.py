@@ -59,10 +59,11 @@ class HipUNet:
         # ln_*): the to_out / ff.net.2 / proj_in epilogue emits the row statistics of the hidden state it writes, the to_q|k|v /
         # attn2.to_q / GEGLU projection runs on the raw hidden state with gamma folded into its weights.  210 LayerNorm launches per
         # TryonNet forward disappear (GarmentNet keeps norm1: its output is the exported feature).  Needs the 16-bit stream.
-        # OFF by default -- measured (profiles/r03_lnfold_probe.log, r03_bench_ab_lnfold_*.json): the producer side is free (+1 us) and
-        # attn2.to_q gains (LayerNorm 10.2 us -> +4.6 us), but every consumer TILE re-folds its rows' partials and re-reads s / c, which
-        # costs the many-tile consumers more than the LayerNorm launch they replace (QKV +12 us, GEGLU +16.5 us at M = 3072):
-        # 1.45 vs 1.50 images/s.  Results are identical in tolerance either way (tests/kernel_checks.py::check_ln_fold).
+        # OFF by default -- measured twice.  Per-consumer-tile fold of the partials (profiles/r03_lnfold_probe.log): QKV +12 us, GEGLU
+        # +16.5 us per launch, 1.45 vs 1.50 images/s.  One fold per row by the producer's last-arriving tile (the form kept, C ABI v5;
+        # profiles/r03_lnfold_final_stats_probe.log): consumers +2..+20 us of epilogue arithmetic, producers +5..+11 us for the
+        # in-launch hand-off (a returning device-scope atomic per tile), against ~8-10 us per LayerNorm launch removed: 1.465 vs
+        # 1.455 / 1.505.  Results are identical in tolerance either way (tests/kernel_checks.py::check_ln_fold).
         self.fuse_ln = bool(fuse_ln) and not self.stream_f32
         self._rowstats = {}
         # attn_fp8 (BASELINE.json configs[4]: "fp16 + fp8 MFMA attention"): every self-attention (attn1) runs on e4m3 operands through
@@ -249,7 +250,7 @@ class HipUNet:
         vt = torch.empty(B, C, N, dtype=dt, device=dev)
         # q columns leave the GEMM multiplied by softmax_scale * log2(e) (fp32, before the one rounding to the storage dtype)
         if fuse and self.tryon:                                  # norm1 folded into the QKV projection
-            ops.linear(hs, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE, ln=(rs, blk["qkv_cv"], 1e-5))
+            ops.linear(hs, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE, ln=(rs, blk["qkv_cv"]))
         else:
             n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
             if feat is not None:
@@ -287,7 +288,7 @@ class HipUNet:
         hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
         # cross attention
         if fuse:                                                 # norm2 folded into attn2.to_q
-            q2 = ops.linear(hs, blk["q2_w"], ln=(rs, blk["q2_cv"], 1e-5))
+            q2 = ops.linear(hs, blk["q2_w"], ln=(rs, blk["q2_cv"]))
         else:
             n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
             q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
@@ -302,7 +303,7 @@ class HipUNet:
         hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
         # feed-forward (GEGLU fused into the first GEMM's epilogue)
         if fuse:                                                 # norm3 folded into the GEGLU projection
-            gg = ops.linear(hs, blk["ff1_w"], bias=blk["ff1_b"], geglu=True, ln=(rs, blk["ff1_cv"], 1e-5))
+            gg = ops.linear(hs, blk["ff1_w"], bias=blk["ff1_b"], geglu=True, ln=(rs, blk["ff1_cv"]))
         else:
             n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
             gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
@@ -312,10 +313,11 @@ class HipUNet:
         return hs
 
     def _rowstats_buf(self, M, C):
-        """fp32 [M][C/32][2] scratch for the LayerNorm row statistics (producer GEMM -> consumer GEMM), one per shape."""
+        """Scratch of the LayerNorm fold (ops.RowStats: producer GEMM -> consumer GEMM), one per shape: this UNet's launches are
+        ordered on one stream, and the other UNet of the pipeline has its own."""
         key = (M, C)
         if key not in self._rowstats:
-            self._rowstats[key] = torch.empty(M * (C // 32) * 2, dtype=torch.float32, device=self.device)
+            self._rowstats[key] = ops.RowStats(M, C, self.device, eps=1e-5)
         return self._rowstats[key]
 
     def _transformer(self, p, x, B, H, W, ctx, garment, feats_out, stop_after_feats=None):

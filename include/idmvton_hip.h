@@ -95,12 +95,17 @@ typedef struct {
        ff.net.0.proj).  LN(x).W^T = rstd[m] * (x . (gamma*W)^T)[m][n] - rstd[m]*mean[m]*s[n] + c[n],  s[n] = sum_k (gamma*W)[n][k],
        c[n] = sum_k beta[k] W[n][k]: the CONSUMER GEMM runs on the raw hidden state with gamma folded into its weights and applies the
        per-row / per-column terms to its accumulators before the rest of the epilogue; the per-row statistics come from the PRODUCER
-       GEMM (the to_out / ff.net.2 / proj_in that wrote x), which emits, for every row m and 32-column group j, the (sum, sum of
-       squares) of the values it STORED: rowstats_out[(m*parts + j)*2 + {0,1}], parts = N/32 (N % 32 == 0, plain 16-byte epilogue).
-       The consumer folds the `ln_parts` partials of its rows in a fixed order (deterministic), with ln_C = parts*32 columns and
-       ln_eps; ln_colvec = [2][N] fp32 {s, c}.  No LayerNorm launch, no normalised copy of x in HBM.  All NULL = off. */
-    float* rowstats_out;
-    const float* ln_rowstats; const float* ln_colvec; int32_t ln_parts; float ln_eps;
+       GEMM (the to_out / ff.net.2 / proj_in that wrote x).  Every tile of the producer emits, for its rows m and 32-column groups j,
+       the (sum, sum of squares) of the values it STORED: rowstats_out[(m*parts + j)*2 + {0,1}], parts = N/32 (N % 32 == 0, plain
+       16-byte epilogue), as write-through agent-scope stores, then counts itself on rowstats_counter[row tile]; the tile that arrives
+       LAST on a row tile folds that tile's partials in a fixed order (deterministic, whichever tile is last) into
+       rowstats_final[m*2 + {0,1}] = (rstd, -rstd*mean) with rowstats_eps, and resets the counter -- ONE fold per row instead of one
+       per consumer tile.  rowstats_counter: >= ceil(M/64) uint32 words, ZERO before the first launch that uses them (every launch
+       leaves them zero), never shared by two launches that may run concurrently.  The consumer reads ln_rowstats = that [M][2] array
+       (one 8-byte load per row, issued ahead of its main loop) and ln_colvec = [2][N] fp32 {s, c}.  No LayerNorm launch, no
+       normalised copy of x in HBM.  All NULL = off. */
+    float* rowstats_out; float* rowstats_final; uint32_t* rowstats_counter; float rowstats_eps;
+    const float* ln_rowstats; const float* ln_colvec;
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */
