@@ -695,6 +695,12 @@ def all_checks(dev="cuda"):
         add("attn_self_2seg_cfg_N768", lambda dt=dt: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2))
         add("attn_self_2seg_ragged_N200", lambda dt=dt: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1))
         add("attn_self_big_logits", lambda dt=dt: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0))
+        # the lazy running max of the ping-pong kernel: logits that climb tile after tile (moves on both halves of a tile), and jumps of
+        # hundreds of binades above the standing max (exp2 overflows to +inf before the max is moved)
+        add("attn_self_pp_big_logits_N2048", lambda dt=dt: check_attn_self(2, 4, 2048, dt, dev, n_garm=2048, b0=1, scale=4.0, tune=(2 << 16) | (2 << 8) | 8))
+        add("attn_self_pp_huge_logits_N2048", lambda dt=dt: check_attn_self(2, 4, 2048, dt, dev, n_garm=2048, b0=1, scale=12.0, tune=(2 << 16) | (2 << 8) | 8))
+        add("attn_self_pp_deep_huge_logits_N2048", lambda dt=dt: check_attn_self(2, 4, 2048, dt, dev, n_garm=2048, b0=1, scale=12.0, tune=(3 << 16) | (2 << 8) | 8, prescaled=True))
+        add("attn_self_pp_huge_logits_ragged_N1000", lambda dt=dt: check_attn_self(2, 4, 1000, dt, dev, n_garm=1000, b0=1, scale=12.0, tune=(2 << 16) | (2 << 8) | 8))
         add("attn_self_N3072_h10", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2))
         add("attn_self_N16", lambda dt=dt: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1))
         # BASELINE.json configs[3] (1024x1536): the two-segment walks of TryonNet at 6144 + 6144 keys (L1) and 1536 + 1536 (L2)
