@@ -311,8 +311,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_kernel(const AttnParams p) {
 // same number of barriers (2 per tile + 2).
 // LDS stage s = { K tile s | V^T tile s-1 } (16 KiB): exactly what MFMA block s reads (group 0 in phase 2s, group 1 in phase
 // 2s+1), filled by LDS-DMA ST-1 stages ahead by all 8 waves (2 instructions each), counted vmcnt across the raw barriers.
-// The kernel is VALU-ISSUE bound (PMC, profiles/r02_pmc_attn_v1_sq.txt: 155 VALU instructions per 16 MFMAs, SIMD issue 83 % busy,
-// matrix pipe 41 %), so the softmax is stripped to the instructions that cannot be avoided:
+// PMC (profiles/r02_pmc_attn_v1_sq.txt): 155 VALU instructions per 16 MFMAs, SIMD issue 83 % busy, matrix pipe 41 %; the softmax was
+// stripped on that reading (below).  Round 3 showed the block is NOT issue bound: three exact forms with a quarter fewer VALU instructions
+// (packed fma; no row max per tile) ran +-0 ... +10 % (profiles/r03_attn_softmax_forms_quick_attn.log, r03_attn_lazy_max_experiment.patch) --
+// what bounds a tile is its dependent chain between the two barriers (MFMA -> exp -> sum -> convert -> MFMA), so extra branches cost
+// and fewer instructions do not pay.  What the softmax does:
 //   * Q arrives (or is made) pre-multiplied by softmax_scale * log2(e): S is already in log2 units;
 //   * the running max is SUBTRACTED BY THE MFMA: the first QK^T MFMA of a tile takes C = -m (16 registers holding this
 //     lane's -m_run, rewritten only when the max moves), so S' = S - m_run comes out of the matrix pipe and P = exp2(S') is
