@@ -197,3 +197,33 @@ def test_outputs_are_invariant_to_world_size(tmp_path):
     assert set(one) == set(two) == {"0", "1"}
     assert one == two, (one, two)
     assert one["0"] != one["1"]                                                # different images really differ
+
+
+def test_bench_refuses_a_rank_count_it_was_not_launched_with():
+    """bench.py --gpus N under a launcher that started a different WORLD_SIZE must not report a number for N (the driver computes
+    scaling from per-N lines); and on a box without a GPU it says so instead of falling back to anything."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    if not torch.cuda.is_available():
+        env.pop("WORLD_SIZE")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+        assert "{" not in r.stdout                          # no JSON line
+
+
+def test_bench_shutdown_has_a_deadline():
+    """The teardown helper returns when the process group goes down normally and cancels its watchdog."""
+    import threading
+    sys.path.insert(0, ROOT)
+    import bench
+    from idm_vton_amd import dist as pd
+    n0 = threading.active_count()
+    bench._shutdown_with_deadline(pd, seconds=30.0)
+    import time
+    t0 = time.time()
+    while threading.active_count() > n0 and time.time() - t0 < 5.0:      # a cancelled Timer thread ends on its own, promptly
+        time.sleep(0.05)
+    assert threading.active_count() <= n0
