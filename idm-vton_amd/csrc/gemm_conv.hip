@@ -22,318 +22,10 @@
 // LIN = plain Linear (one K segment, no spatial gather): the activation operand's DMA offsets are precomputed like the
 // weight's, so issuing a tile costs one add per DMA instead of the ~12 VALU of the conv gather.
 #include <cstdlib>
+#include <type_traits>
 #include "common.cuh"
 
-struct GemmParams {
-    const void* w; uint32_t w_bytes; int N; int Ktot;
-    int nseg; idmvton_seg seg[IDMVTON_MAX_SEG];
-    int M, Ho, Wo, Hi, Wi, stride, ups;
-    void* out; int ldo;
-    const void* bias; const void* rowbias; int rowbias_ld; int rows_per_group;
-    const void* res; int ldr;
-    int mode;
-    void* vt; int vt_n0; int vt_tokens; int vt_perm;
-    int colscale_n; float colscale;
-    int tiles_m, tiles_n;
-    int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
-    int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
-    float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
-    float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
-    const float* ln_rowstats; const float* ln_colvec;    // consumer: LayerNorm folded into this GEMM (ln_rowstats = a producer's rs_final)
-};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Two accumulator column groups (g = 2gp, 2gp+1: columns 8g + 4u + j) of one 32x32 tile -> 8 CONSECUTIVE columns 16gp + 8u + (0..7)
-// of the lane's row: lanes 32..63 of group 2gp trade places with lanes 0..31 of group 2gp+1 (v_permlane32_swap).  The epilogue is
-// store-issue bound (one row per lane: every lane's store is its own memory segment), so 16-byte accesses halve its instruction
-// count at the same bytes.  Both lanes of a pair (l, l+32) share their row, so they are active together.
-__device__ __forceinline__ void swap_cols8(const f32x16& c, const int gp, float (&v)[8]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * gp + j]), __float_as_uint(c[8 * gp + 4 + j]), false, false);
-        v[j] = __uint_as_float(r[0]);
-        v[4 + j] = __uint_as_float(r[1]);
-    }
-}
-
-// Epilogue shared by every main loop: acc[ni][mi] is the wave's (SN x SM) sub-tile as NI x MI 32x32 accumulators (TR: D[m][n]).
-template <typename T, int NI, int MI, int SN, int SM, bool TR>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[NI][MI], const int m0, const int n0, const int wn, const int wm,
-                                              const int lane, const float* fin) {
-    // Folded LayerNorm (fin != nullptr, block-uniform): every accumulator value a of row m, column n becomes
-    //     rstd[m] * a - rstd[m]*mean[m] * s[n] + c[n]        ((rstd, -rstd*mean) = fin[2*row_in_tile ..], s = ln_colvec, c = ln_colvec + N)
-    // right where it is consumed (8 / 4 values at a time, like the bias): a separate pass over the accumulators costs 30-90 extra
-    // registers (the loads get clustered) and spills the 256x256 tile.
-    const float* lcs = p.ln_colvec;
-    const float* lcc = p.ln_colvec + p.N;
-    auto ln8 = [&](float (&v)[8], const float2 ab, const int n) {
-        const float4 s0 = *(const float4*)(lcs + n), s1 = *(const float4*)(lcs + n + 4);
-        const float4 c0 = *(const float4*)(lcc + n), c1 = *(const float4*)(lcc + n + 4);
-        v[0] = fmaf(v[0], ab.x, fmaf(ab.y, s0.x, c0.x)); v[1] = fmaf(v[1], ab.x, fmaf(ab.y, s0.y, c0.y));
-        v[2] = fmaf(v[2], ab.x, fmaf(ab.y, s0.z, c0.z)); v[3] = fmaf(v[3], ab.x, fmaf(ab.y, s0.w, c0.w));
-        v[4] = fmaf(v[4], ab.x, fmaf(ab.y, s1.x, c1.x)); v[5] = fmaf(v[5], ab.x, fmaf(ab.y, s1.y, c1.y));
-        v[6] = fmaf(v[6], ab.x, fmaf(ab.y, s1.z, c1.z)); v[7] = fmaf(v[7], ab.x, fmaf(ab.y, s1.w, c1.w));
-    };
-    auto ln4 = [&](float (&v)[4], const float2 ab, const int n) {
-        const float4 s0 = *(const float4*)(lcs + n), c0 = *(const float4*)(lcc + n);
-        v[0] = fmaf(v[0], ab.x, fmaf(ab.y, s0.x, c0.x)); v[1] = fmaf(v[1], ab.x, fmaf(ab.y, s0.y, c0.y));
-        v[2] = fmaf(v[2], ab.x, fmaf(ab.y, s0.z, c0.z)); v[3] = fmaf(v[3], ab.x, fmaf(ab.y, s0.w, c0.w));
-    };
-    typedef typename VT<T>::v4 v4;
-    typedef typename VT<T>::v8 v8;
-    const int u = lane >> 5, l31 = lane & 31;
-    const T* bias = (const T*)p.bias;
-    if constexpr (TR) {
-        if (p.vt_perm) {
-            // key order puts the tokens of accumulator groups g = 2gp, 2gp+1 (rows 8g + 4u + j) next to each other: 16 gp + 8u + 4(g&1) + j
-            T* vt = (T*)p.vt;
-            const int Cv = p.N - p.vt_n0;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int n = n0 + wn * SN + ni * 32 + l31;
-                if (n >= p.N) continue;
-                const float bv = bias ? (float)bias[n] : 0.f;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const int m = m0 + wm * SM + mi * 32 + 16 * gp;                  // vt_tokens % 16 == 0: one batch per 16 rows
-                        if (m >= p.M) continue;
-                        const int b = m / p.vt_tokens;
-                        const int tok = m - b * p.vt_tokens + 8 * u;
-                        v8 o;
-                        if (fin) {                         // registers 8gp + j <-> rows 16gp + 4u + (j & 3) + 8 (j >> 2) of this 32-row tile
-                            const float sn = lcs[n], cn = lcc[n];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 16 * gp + 4 * u + (j & 3) + 8 * (j >> 2)) * 2);
-                                acc[ni][mi][8 * gp + j] = fmaf(acc[ni][mi][8 * gp + j], ab.x, fmaf(ab.y, sn, cn));
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (T)(acc[ni][mi][8 * gp + j] + bv);
-                        *(v8*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
-                    }
-            }
-            return;
-        }
-        // acc[ni][mi] = D[m][n]: column n = l31, rows m = 8g + 4u + j.  vt[(b*Cv + n - vt_n0)*tokens + tok..tok+3]
-        T* vt = (T*)p.vt;
-        const int Cv = p.N - p.vt_n0;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * SN + ni * 32 + l31;
-            if (n >= p.N) continue;
-            const float bv = bias ? (float)bias[n] : 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int m = m0 + wm * SM + mi * 32 + 8 * g + 4 * u;
-                    if (m >= p.M) continue;
-                    const int b = m / p.vt_tokens;
-                    int tok = m - b * p.vt_tokens;
-                    // attention key order: bits 2 and 3 of the token index swapped inside every group of 16, so that the 8 keys a
-                    // half-wave contracts in one PV MFMA (QK^T accumulator rows 8g+4u..+3, g = 0,1) are 16 contiguous bytes of V^T
-                    if (p.vt_perm) tok = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
-                    v4 o;
-                    if (fin) {
-                        const float sn = lcs[n], cn = lcc[n];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 8 * g + 4 * u + j) * 2);
-                            acc[ni][mi][4 * g + j] = fmaf(acc[ni][mi][4 * g + j], ab.x, fmaf(ab.y, sn, cn));
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
-                    *(v4*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
-                }
-        }
-        return;
-    }
-    T* out = (T*)p.out;
-    const T* res = (const T*)p.res;
-    const T* rowbias = (const T*)p.rowbias;
-    if (p.wide) {                                        // block-uniform: 16-byte loads / stores, 8 columns per lane and access
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = m0 + wm * SM + mi * 32 + l31;
-            if (m >= p.M) continue;
-            const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
-            const float2 ab = fin ? *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2) : make_float2(1.f, 0.f);
-            if (p.mode == IDMVTON_EPI_GEGLU) {
-                if constexpr (NI % 2 == 0) {
-#pragma unroll
-                    for (int pr = 0; pr < NI / 2; ++pr)
-#pragma unroll
-                        for (int gp = 0; gp < 2; ++gp) {
-                            float h[8], gt[8];
-                            swap_cols8(acc[2 * pr][mi], gp, h);
-                            swap_cols8(acc[2 * pr + 1][mi], gp, gt);
-                            const int nh = n0 + wn * SN + pr * 64 + 16 * gp + 8 * u;   // h rows; gate rows are nh + 32
-                            if (nh + 32 >= p.N) continue;
-                            if (fin) { ln8(h, ab, nh); ln8(gt, ab, nh + 32); }
-                            const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 16 * gp + 8 * u;
-                            if (bias) {
-                                const v8 bh = *(const v8*)(bias + nh), bg = *(const v8*)(bias + nh + 32);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) { h[j] += (float)bh[j]; gt[j] += (float)bg[j]; }
-                            }
-                            v8 o;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (T)(h[j] * gelu_erf(gt[j]));
-                            *(v8*)(out + (size_t)m * p.ldo + jo) = o;
-                        }
-                }
-                continue;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                float rs1 = 0.f, rs2 = 0.f;                // LayerNorm row statistics of the values stored below (this lane: 16 of the 32 columns)
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    float v[8];
-                    swap_cols8(acc[ni][mi], gp, v);
-                    const int n = n0 + wn * SN + ni * 32 + 16 * gp + 8 * u;
-                    if (n >= p.N) continue;
-                    if (fin) ln8(v, ab, n);
-                    if (bias) {
-                        const v8 bb = *(const v8*)(bias + n);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)bb[j];
-                    }
-                    if (rb) {
-                        const v8 bb = *(const v8*)(rb + n);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)bb[j];
-                    }
-                    if (n < p.colscale_n) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] *= p.colscale;
-                    }
-                    if (p.mode == IDMVTON_EPI_GELU) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-                    } else if (p.mode == IDMVTON_EPI_QUICKGELU) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
-                    }
-                    if (res) {
-                        if (p.res32) {                     // block-uniform: the fp32 residual stream
-                            const float4* rp = (const float4*)((const float*)p.res + (size_t)m * p.ldr + n);
-                            const float4 r0 = rp[0], r1 = rp[1];
-                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                        } else {
-                            const v8 rr = *(const v8*)(res + (size_t)m * p.ldr + n);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
-                        }
-                    }
-                    if (p.out32) {
-                        float4* op = (float4*)((float*)p.out + (size_t)m * p.ldo + n);
-                        op[0] = make_float4(v[0], v[1], v[2], v[3]);
-                        op[1] = make_float4(v[4], v[5], v[6], v[7]);
-                    } else {
-                        v8 o;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
-                        *(v8*)(out + (size_t)m * p.ldo + n) = o;
-                        if (p.rowstats_out) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; rs1 += f; rs2 += f * f; }
-                        }
-                    }
-                }
-                if (p.rowstats_out) {                      // block-uniform; N % 32 == 0, so the whole 32-column group is inside N
-                    rs1 = xhalf_sum(rs1); rs2 = xhalf_sum(rs2);    // lanes l and l + 32 hold the two column halves of the same row
-                    const int grp32 = (n0 + wn * SN + ni * 32) >> 5;
-                    // one aligned 8-byte agent-scope store (write-through): read back by another CU's workgroup inside this launch
-                    if (u == 0 && grp32 < p.rs_parts) st_agent_f2(p.rowstats_out + ((size_t)m * p.rs_parts + grp32) * 2, rs1, rs2);
-                }
-            }
-        }
-        return;
-    }
-    // (128x128-per-wave tiles, NI * MI = 16, exist only with the 16-byte epilogue: this nest no longer unrolls fully there and the
-    //  runtime-indexed accumulators would move to scratch -- 1088 bytes per lane measured; launch_gemm falls back to the 8-wave tile)
-    if constexpr (NI * MI <= 8)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * SM + mi * 32 + l31;
-        if (m >= p.M) continue;
-        const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
-        const float2 ab = fin ? *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2) : make_float2(1.f, 0.f);
-        if (p.mode == IDMVTON_EPI_GEGLU) {
-            if constexpr (NI % 2 == 0) {
-#pragma unroll
-                for (int pr = 0; pr < NI / 2; ++pr)          // 64-row weight blocks [32 h | 32 gate] of this wave
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nh = n0 + wn * SN + pr * 64 + 8 * g + 4 * u;     // h rows; gate rows are nh + 32
-                        if (nh + 32 >= p.N) continue;
-                        const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 8 * g + 4 * u;
-                        v4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float h = acc[2 * pr][mi][4 * g + j], gt = acc[2 * pr + 1][mi][4 * g + j];
-                            if (fin) {
-                                h = fmaf(h, ab.x, fmaf(ab.y, lcs[nh + j], lcc[nh + j]));
-                                gt = fmaf(gt, ab.x, fmaf(ab.y, lcs[nh + 32 + j], lcc[nh + 32 + j]));
-                            }
-                            if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
-                            o[j] = (T)(h * gelu_erf(gt));
-                        }
-                        *(v4*)(out + (size_t)m * p.ldo + jo) = o;
-                    }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * SN + ni * 32 + 8 * g + 4 * u;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-                if (fin) ln4(v, ab, n);
-                if (bias) {
-                    const v4 bb = *(const v4*)(bias + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)bb[j];
-                }
-                if (rb) {
-                    const v4 bb = *(const v4*)(rb + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)bb[j];
-                }
-                if (n < p.colscale_n) {                    // e.g. the q columns of a fused QKV projection: softmax scale in fp32
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= p.colscale;
-                }
-                if (p.mode == IDMVTON_EPI_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                } else if (p.mode == IDMVTON_EPI_QUICKGELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
-                }
-                if (res) {
-                    const v4 rr = *(const v4*)(res + (size_t)m * p.ldr + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
-                }
-                v4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
-                *(v4*)(out + (size_t)m * p.ldo + n) = o;
-            }
-    }
-}
+#include "gemm_common.cuh"
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
@@ -663,9 +355,14 @@ static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC, PFX>), grid, block, 0, st, p);
 }
 
+// gemm_lin.hip: the hand-scheduled 256x256 Linear main loop (variants 4: 4 waves x 128x128, 5: 8 waves x 128x64)
+int launch_gemm_lin(const GemmParams& p, bool bf16, int geometry, int form, hipStream_t st);
+
 template <typename T>
 static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool lin, hipStream_t st) {
     GemmParams p = p0;
+    int form = 0;
+    if (variant == 4 || variant == 5) { form = bm & 15; bm &= ~15; }       // placement form under measurement: low nibble of the BM field
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tiles_m = (p.M + bm - 1) / bm;
     if (variant == 0) {
@@ -690,6 +387,10 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 3 is the 256x256 tile");   // LDS fragment reads
         if (p.wide && !p.vt) launch_cfg<T, 256, 256, 2, 2, 2, true, 1>(p, lin, st);
         else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue or a V^T part: the 8-wave tile
+    } else if (variant == 4 || variant == 5) {           // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
+        if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variants 4 / 5 are the 256x256 tile");
+        if (lin && p.wide && !p.vt && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value, variant, form, st);
+        else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;
