@@ -246,7 +246,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         __syncthreads();
         fin = (const float*)smem;
     }
-    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, fin);
+    gemm_epilogue<T, NI, MI, SN, SM, TR, BN, BM, NW * 64>(p, acc, m0, n0, wn, wm, lane, fin, smem);
 
     if (p.rs_counter) {                                  // block-uniform: producer of LayerNorm row statistics
         // Inter-workgroup hand-off inside the launch (guide G16, "payload write-through + counter"): the partials left as agent-scope
@@ -355,14 +355,14 @@ static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC, PFX>), grid, block, 0, st, p);
 }
 
-// gemm_lin.hip: the hand-scheduled 256x256 Linear main loop (variants 4: 4 waves x 128x128, 5: 8 waves x 128x64)
-int launch_gemm_lin(const GemmParams& p, bool bf16, int geometry, int form, hipStream_t st);
+// gemm_lin.hip: the hand-scheduled 256x256 Linear main loop (variant 5: 8 waves x 128x64)
+int launch_gemm_lin(const GemmParams& p, bool bf16, int form, hipStream_t st);
 
 template <typename T>
 static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool lin, hipStream_t st) {
     GemmParams p = p0;
     int form = 0;
-    if (variant == 4 || variant == 5) { form = bm & 15; bm &= ~15; }       // placement form under measurement: low nibble of the BM field
+    if (variant == 5) { form = bm & 15; bm &= ~15; }       // placement form under measurement: low nibble of the BM field
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tiles_m = (p.M + bm - 1) / bm;
     if (variant == 0) {
@@ -387,9 +387,9 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 3 is the 256x256 tile");   // LDS fragment reads
         if (p.wide && !p.vt) launch_cfg<T, 256, 256, 2, 2, 2, true, 1>(p, lin, st);
         else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue or a V^T part: the 8-wave tile
-    } else if (variant == 4 || variant == 5) {           // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
-        if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variants 4 / 5 are the 256x256 tile");
-        if (lin && p.wide && !p.vt && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, sizeof(T) == 2 && std::is_same<T, bf16_t>::value, variant, form, st);
+    } else if (variant == 5) {                           // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
+        if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 5 is the 256x256 tile");
+        if (lin && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, std::is_same<T, bf16_t>::value, form, st);
         else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
@@ -472,8 +472,11 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     } else CHECK_ARG(!a->ln_colvec, IDMVTON_E_ARG, "gemm_conv: ln_colvec without ln_rowstats");
     p.res32 = (a->io_flags & IDMVTON_IO_RES_F32) ? 1 : 0;
     p.out32 = (a->io_flags & IDMVTON_IO_OUT_F32) ? 1 : 0;
+    p.bias32 = (a->io_flags & IDMVTON_IO_BIAS_F32) ? 1 : 0;
+    if (p.bias32) CHECK_ARG(a->bias && p.wide && !geglu && !a->vt && ((uintptr_t)a->bias & 15) == 0, IDMVTON_E_ARG,
+                            "gemm_conv: IDMVTON_IO_BIAS_F32 needs a 16-byte aligned bias and the plain 16-byte epilogue (no GEGLU, no vt)");
     if (p.res32 || p.out32) {
-        CHECK_ARG((a->io_flags & ~3) == 0 && !geglu && !a->vt, IDMVTON_E_ARG, "gemm_conv: io_flags=%d (fp32 res / out: no GEGLU, no vt)", a->io_flags);
+        CHECK_ARG((a->io_flags & ~7) == 0 && !geglu && !a->vt, IDMVTON_E_ARG, "gemm_conv: io_flags=%d (fp32 res / out: no GEGLU, no vt)", a->io_flags);
         CHECK_ARG(!p.res32 || a->res, IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_RES_F32 without res");
         CHECK_ARG(p.wide, IDMVTON_E_ALIGN, "gemm_conv: the fp32 residual stream needs the 16-byte epilogue (N, ldo, ldr multiples of 8, 16-byte aligned pointers)");
     }

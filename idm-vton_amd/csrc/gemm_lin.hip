@@ -22,8 +22,8 @@
 // Two geometries: 4 waves x (128 x 128) (one wave per SIMD, 256 accumulator registers in AGPRs) and 8 waves x (128 x 64).
 #include "gemm_common.cuh"
 
-template <typename T, int MI, int DMA_SPLIT, int WAIT_AT>
-__device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem) {
+template <typename T, int MI, int DMA_SPLIT, int WAIT_AT, int PRIO, bool TR>
+__device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     constexpr int BN = 256, BM = 256, NI = 4, SN = 128, SM = MI * 32;
     constexpr int WM = BM / SM, NW = 2 * WM;             // waves: 2 along n x WM along m
@@ -31,17 +31,6 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem) {
     constexpr int OPB = 256 * 128;                       // bytes of one operand tile stage
     constexpr int BUF = 2 * OPB;                         // LDS map: [W0 | X0 | W1 | X1]
 
-    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    int tm, tn;
-    {   // grouped raster (gemm_conv_kernel): an XCD's concurrent tiles form a ~1024-row output patch
-        constexpr int GM = 1024 / BM;
-        const int width = GM * p.tiles_n;
-        const int grp = wg / width, rem = wg - grp * width;
-        const int first = grp * GM;
-        const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
-        tn = rem / gsz; tm = first + (rem - tn * gsz);
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63;
     const int wave = uniform(threadIdx.x >> 6);
     const int wn = wave / WM, wm = wave % WM;
@@ -99,7 +88,7 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem) {
 #pragma unroll
         for (int idx = i0; idx < i1; ++idx) {
             const int ni = idx / MI, mi = idx % MI;
-            acc[ni][mi] = VT<T>::mfma(fa[set][ni], fb[set][mi], acc[ni][mi]);
+            acc[ni][mi] = TR ? VT<T>::mfma(fb[set][mi], fa[set][ni], acc[ni][mi]) : VT<T>::mfma(fa[set][ni], fb[set][mi], acc[ni][mi]);
         }
     };
     constexpr int NMF = NI * MI;                         // MFMAs per k-step (16 | 8)
@@ -123,6 +112,7 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem) {
     asm volatile("" ::: "memory");
     read_all(0, 0, 0);
 
+    if constexpr (PRIO == 1) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }   // static priority for the second-dispatched half (guide T5)
     int cur = 0;                                         // byte offset of the buffer being computed (0 | BUF)
     for (int t = 0; t + 1 < nt; ++t) {
         const int nxt = cur ^ BUF;
@@ -185,31 +175,44 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_range(1, 0, NMF);
 
-    gemm_epilogue<T, NI, MI, SN, SM, false>(p, acc, m0, n0, wn, wm, lane, nullptr);
+    gemm_epilogue<T, NI, MI, SN, SM, TR, BN, BM, NW * 64>(p, acc, m0, n0, wn, wm, lane, nullptr, smem);
 }
 
-template <typename T, int MI, int DMA_SPLIT, int WAIT_AT>
+template <typename T, int MI, int DMA_SPLIT, int WAIT_AT, int PRIO>
 __global__ __launch_bounds__(MI == 4 ? 256 : 512, MI == 4 ? 1 : 2) void gemm_lin_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * 256 * 128];
-    gemm_lin_body<T, MI, DMA_SPLIT, WAIT_AT>(p, smem);
+    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tm, tn;
+    {   // grouped raster (gemm_conv_kernel): an XCD's concurrent tiles form a ~1024-row output patch
+        constexpr int GM = 4;
+        const int width = GM * p.tiles_n;
+        const int grp = wg / width, rem = wg - grp * width;
+        const int first = grp * GM;
+        const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
+        tn = rem / gsz; tm = first + (rem - tn * gsz);
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_lin_body<T, MI, DMA_SPLIT, WAIT_AT, PRIO, true>(p, smem, m0, n0);   // block-uniform: the V^T part of a fused QKV
+    else gemm_lin_body<T, MI, DMA_SPLIT, WAIT_AT, PRIO, false>(p, smem, m0, n0);
 }
 
-// Called by gemm_conv.hip's launch_gemm for tile_hint variants 4 (4 waves x 128x128) and 5 (8 waves x 128x64); `form` (the low
-// nibble of tile_hint's BM field, always 0 for a 256-row tile) selects the placement under measurement.  Preconditions checked by
-// the caller: plain Linear (one K segment, no gather), 16-byte epilogue, no transposed part, no folded LayerNorm.
+// Called by gemm_conv.hip's launch_gemm for tile_hint variant 5 (8 waves x 128x64); `form` (the low nibble of tile_hint's BM field, always 0
+// for a 256-row tile) selects the placement under measurement.  Preconditions checked by the caller: plain Linear (one K segment, no
+// gather), 16-byte epilogue (or a V^T part), no folded LayerNorm.  (Variant 4 = 4 waves x 128x128, one wave per SIMD, was measured in
+// round 4 and removed: 887-913 TFLOP/s on the 3072x10240x1280 GEGLU against 989-1008 for this geometry -- an LDS-DMA instruction costs
+// its wave ~60 issue cycles, twice an MFMA gap, and with one wave per SIMD nobody else feeds the matrix pipe meanwhile.)
 template <typename T>
-static int launch_lin(const GemmParams& p, int geometry, int form, hipStream_t st) {
-    const dim3 grid(p.tiles_n * p.tiles_m);
-    if (geometry == 4) {
-        if (form == 0) hipLaunchKernelGGL((gemm_lin_kernel<T, 4, 0, 4>), grid, dim3(256), 0, st, p);
-        else if (form == 1) hipLaunchKernelGGL((gemm_lin_kernel<T, 4, 1, 4>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_lin_kernel<T, 4, 0, 8>), grid, dim3(256), 0, st, p);
-    } else {
-        if (form == 0) hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 0, 2>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 1, 2>), grid, dim3(512), 0, st, p);
+static int launch_lin(const GemmParams& p, int form, hipStream_t st) {
+    const dim3 grid(p.tiles_n * p.tiles_m), block(512);
+    switch (form) {
+    case 0: hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 0, 2, 0>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 1, 0, 0>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 1, 4, 0>), grid, block, 0, st, p); break;
+    case 4: hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 1, 2, 1>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_lin_kernel<T, 2, 1, 2, 0>), grid, block, 0, st, p); break;
     }
     return 0;
 }
-int launch_gemm_lin(const GemmParams& p, bool bf16, int geometry, int form, hipStream_t st) {
-    return bf16 ? launch_lin<bf16_t>(p, geometry, form, st) : launch_lin<f16_t>(p, geometry, form, st);
+int launch_gemm_lin(const GemmParams& p, bool bf16, int form, hipStream_t st) {
+    return bf16 ? launch_lin<bf16_t>(p, form, st) : launch_lin<f16_t>(p, form, st);
 }

@@ -106,9 +106,27 @@ extern "C" int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream) 
 // lanes, one (sum, sumsq) partial per (block, batch, group) in HBM, folded in block order by gn_finalize_kernel.  Results
 // are therefore bit-reproducible run to run (the parity tests compare execution modes bit for bit).
 #define GN_MAXC 2560
-template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_args a, int pix_per_block, int nblk) {
+// 8 consecutive channels of one pixel as fp32: from a 16-bit tensor (one 16-byte load) or, X32, from an fp32 one (two) -- the
+// split-precision VAE path keeps its residual stream and convolution outputs in fp32 (include/idmvton_hip.h, IDMVTON_GN_*)
+template <typename T, bool X32> struct GnLoad {
     typedef typename VT<T>::v8 v8;
+    struct raw { v8 t; };
+    static __device__ __forceinline__ raw ld(const void* base, size_t idx) { raw r; r.t = *(const v8*)((const T*)base + idx); return r; }
+    static __device__ __forceinline__ float get(const raw& r, int j) { return (float)r.t[j]; }
+};
+template <typename T> struct GnLoad<T, true> {
+    struct raw { float4 a, b; };
+    static __device__ __forceinline__ raw ld(const void* base, size_t idx) {
+        raw r; const float4* p = (const float4*)((const float*)base + idx); r.a = p[0]; r.b = p[1]; return r;
+    }
+    static __device__ __forceinline__ float get(const raw& r, int j) {
+        return j == 0 ? r.a.x : j == 1 ? r.a.y : j == 2 ? r.a.z : j == 3 ? r.a.w : j == 4 ? r.b.x : j == 5 ? r.b.y : j == 6 ? r.b.z : r.b.w;
+    }
+};
+
+template <typename T, bool X32>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_args a, int pix_per_block, int nblk) {
+    typedef GnLoad<T, X32> L;
     __shared__ float red_s[GN_MAXC], red_q[GN_MAXC];     // [pixel lane][channel] (tpp * C <= 2048) or [channel] (C > 2048)
     const int b = blockIdx.y;
     const int nchunk = a.C >> 3;
@@ -119,9 +137,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_a
     // chunks beyond 256 threads (C > 2048, tpp == 1): each thread also owns chunk + 256
     for (int cb = chunk; cb < nchunk; cb += 256) {
         const int c0 = cb * 8;
-        const T* src; int pitch, coff;
-        if (c0 < a.C1) { src = (const T*)a.x; pitch = a.C1; coff = c0; }
-        else { src = (const T*)a.x2; pitch = a.C - a.C1; coff = c0 - a.C1; }
+        const void* src; int pitch, coff;
+        if (c0 < a.C1) { src = a.x; pitch = a.C1; coff = c0; }
+        else { src = a.x2; pitch = a.C - a.C1; coff = c0 - a.C1; }
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
@@ -130,18 +148,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const idmvton_groupnorm_a
             // otherwise); accumulation order per thread is unchanged, so results are bit-identical to the rolled loop
             int pix = p0 + psub;
             for (; pix + 3 * tpp < p1; pix += 4 * tpp) {
-                v8 t[4];
+                typename L::raw t[4];
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) t[u4] = *(const v8*)(src + ((size_t)b * a.HW + pix + u4 * tpp) * pitch + coff);
+                for (int u4 = 0; u4 < 4; ++u4) t[u4] = L::ld(src, ((size_t)b * a.HW + pix + u4 * tpp) * pitch + coff);
 #pragma unroll
                 for (int u4 = 0; u4 < 4; ++u4)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = (float)t[u4][j]; s[j] += f; q[j] += f * f; }
+                    for (int j = 0; j < 8; ++j) { const float f = L::get(t[u4], j); s[j] += f; q[j] += f * f; }
             }
             for (; pix < p1; pix += tpp) {
-                const v8 t = *(const v8*)(src + ((size_t)b * a.HW + pix) * pitch + coff);
+                const typename L::raw t = L::ld(src, ((size_t)b * a.HW + pix) * pitch + coff);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)t[j]; s[j] += f; q[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { const float f = L::get(t, j); s[j] += f; q[j] += f * f; }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { red_s[psub * a.C + c0 + j] = s[j]; red_q[psub * a.C + c0 + j] = q[j]; }
@@ -192,9 +210,11 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(double* stats, int bg, 
     }
 }
 
-template <typename T>
+// PREC = the split-precision form (flags = X_F32 | Y_SPLIT | AFFINE_F32): fp32 input, fp32 gamma / beta, output [hi | lo] with pixel pitch 2C
+template <typename T, bool PREC>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_args a, int pix_per_block) {
     typedef typename VT<T>::v8 v8;
+    typedef GnLoad<T, PREC> L;
     const int b = blockIdx.y;
     const int nchunk = a.C >> 3;
     const int tpp = 256 / nchunk > 0 ? 256 / nchunk : 1;
@@ -202,51 +222,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const idmvton_groupnorm_a
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, a.HW);
     const int cpg = a.C / a.groups;
-    const T* gamma = (const T*)a.gamma;
-    const T* beta = (const T*)a.beta;
+    const int opitch = PREC ? 2 * a.C : a.C;
     for (int cb = chunk; cb < nchunk; cb += 256) {
         const int c0 = cb * 8;
-        const T* src; int pitch, coff;
-        if (c0 < a.C1) { src = (const T*)a.x; pitch = a.C1; coff = c0; }
-        else { src = (const T*)a.x2; pitch = a.C - a.C1; coff = c0 - a.C1; }
+        const void* src; int pitch, coff;
+        if (c0 < a.C1) { src = a.x; pitch = a.C1; coff = c0; }
+        else { src = a.x2; pitch = a.C - a.C1; coff = c0 - a.C1; }
         float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c0 + j, g = c / cpg;
             const float2 mr = *(const float2*)(a.stats + ((size_t)b * a.groups + g) * 2);      // (mean, rstd) from gn_finalize_kernel
-            sc[j] = mr.y * (float)gamma[c];
-            sh[j] = (float)beta[c] - mr.x * sc[j];
+            const float gm = PREC ? ((const float*)a.gamma)[c] : (float)((const T*)a.gamma)[c];
+            const float bt = PREC ? ((const float*)a.beta)[c] : (float)((const T*)a.beta)[c];
+            sc[j] = mr.y * gm;
+            sh[j] = bt - mr.x * sc[j];
         }
+        auto emit = [&](const typename L::raw& t, size_t row) {
+            T* dst = (T*)a.y + row * opitch + c0;
+            v8 o, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = L::get(t, j) * sc[j] + sh[j];
+                if (a.silu) f = silu_f(f);
+                o[j] = (T)f;
+                if constexpr (PREC) lo[j] = (T)(f - (float)o[j]);
+            }
+            *(v8*)dst = o;
+            if constexpr (PREC) *(v8*)(dst + a.C) = lo;
+        };
         if (psub < tpp) {
-            T* dst = (T*)a.y;
             int pix = p0 + psub;
             for (; pix + 3 * tpp < p1; pix += 4 * tpp) {          // four pixels' loads in flight per thread
-                v8 t[4];
+                typename L::raw t[4];
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) t[u4] = *(const v8*)(src + ((size_t)b * a.HW + pix + u4 * tpp) * pitch + coff);
+                for (int u4 = 0; u4 < 4; ++u4) t[u4] = L::ld(src, ((size_t)b * a.HW + pix + u4 * tpp) * pitch + coff);
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) {
-                    v8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float f = (float)t[u4][j] * sc[j] + sh[j];
-                        if (a.silu) f = silu_f(f);
-                        o[j] = (T)f;
-                    }
-                    *(v8*)(dst + ((size_t)b * a.HW + pix + u4 * tpp) * a.C + c0) = o;
-                }
+                for (int u4 = 0; u4 < 4; ++u4) emit(t[u4], (size_t)b * a.HW + pix + u4 * tpp);
             }
             for (; pix < p1; pix += tpp) {
                 const size_t row = (size_t)b * a.HW + pix;
-                const v8 t = *(const v8*)(src + row * pitch + coff);
-                v8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float f = (float)t[j] * sc[j] + sh[j];
-                    if (a.silu) f = silu_f(f);
-                    o[j] = (T)f;
-                }
-                *(v8*)(dst + row * a.C + c0) = o;
+                emit(L::ld(src, row * pitch + coff), row);
             }
         }
     }
@@ -267,10 +283,13 @@ static int launch_gn(const idmvton_groupnorm_args& a, hipStream_t st) {
     int nblk, ppb;
     gn_geometry(a, nblk, ppb);
     const dim3 grid(nblk, a.B), block(256);
-    hipLaunchKernelGGL((gn_stats_kernel<T>), grid, block, 0, st, a, ppb, nblk);
+    const bool prec = a.flags != 0;
+    if (prec) hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, block, 0, st, a, ppb, nblk);
+    else hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, block, 0, st, a, ppb, nblk);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B * a.groups), dim3(64), 0, st, a.stats, a.B * a.groups, nblk,
                        (double)(a.C / a.groups) * (double)a.HW, (double)a.eps);
-    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, block, 0, st, a, ppb);
+    if (prec) hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, block, 0, st, a, ppb);
+    else hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, block, 0, st, a, ppb);
     CHECK_LAUNCH("groupnorm");
     return IDMVTON_OK;
 }
@@ -294,6 +313,9 @@ extern "C" int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream) 
               "groupnorm: stats scratch holds %d doubles, needs %d", a->stats_doubles,
               idmvton_groupnorm_stats_doubles(a->B, a->HW, a->C, a->groups));
     CHECK_ARG(a->C1 > 0 && a->C1 <= a->C && a->C1 % 8 == 0 && (a->C1 == a->C || a->x2), IDMVTON_E_SHAPE, "groupnorm: C1=%d", a->C1);
+    constexpr int PREC_FLAGS = IDMVTON_GN_X_F32 | IDMVTON_GN_Y_SPLIT | IDMVTON_GN_AFFINE_F32;
+    CHECK_ARG(a->flags == 0 || a->flags == PREC_FLAGS, IDMVTON_E_ARG, "groupnorm: flags=%d (0, or the split-precision form X_F32 | Y_SPLIT | AFFINE_F32 = %d)", a->flags, PREC_FLAGS);
+    if (a->flags) CHECK_ARG((((uintptr_t)a->gamma | (uintptr_t)a->beta) & 3) == 0, IDMVTON_E_ALIGN, "groupnorm: fp32 gamma / beta alignment");
     CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->x2 | (uintptr_t)a->y) & 15) == 0, IDMVTON_E_ALIGN, "groupnorm: pointer alignment");
     return a->dtype == IDMVTON_BF16 ? launch_gn<bf16_t>(*a, (hipStream_t)stream) : launch_gn<f16_t>(*a, (hipStream_t)stream);
 }
@@ -339,12 +361,65 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, 
     }
 }
 
+// Split-precision form: logits fp32 [rows][ld] (read three times from L2), probabilities out as the pair [hi (n) | lo (n)] of T.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* x, int n, int ld, float scale, T* y, int ldy) {
+    typedef typename VT<T>::v8 v8;
+    __shared__ float red[8];
+    const float* row = x + (size_t)blockIdx.x * ld;
+    T* yr = y + (size_t)blockIdx.x * ldy;
+    const int nchunk = n >> 3;
+    const float sl = scale * 1.44269504088896341f;
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const float4 t0 = *(const float4*)(row + c * 8), t1 = *(const float4*)(row + c * 8 + 4);
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(t0.x, t0.y), fmaxf(t0.z, t0.w)), fmaxf(fmaxf(t1.x, t1.y), fmaxf(t1.z, t1.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const float4 t0 = *(const float4*)(row + c * 8), t1 = *(const float4*)(row + c * 8 + 4);
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f((v[j] - mx) * sl);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const float4 t0 = *(const float4*)(row + c * 8), t1 = *(const float4*)(row + c * 8 + 4);
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        v8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = __builtin_amdgcn_exp2f((v[j] - mx) * sl) * inv;
+            hi[j] = (T)p;
+            lo[j] = (T)(p - (float)hi[j]);
+        }
+        *(v8*)(yr + c * 8) = hi;
+        *(v8*)(yr + n + c * 8) = lo;
+    }
+}
+
 extern "C" int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream) {
     CHECK_ARG(a && a->x, IDMVTON_E_ARG, "softmax_rows: null pointer");
     CHECK_ARG(a->dtype == IDMVTON_F16 || a->dtype == IDMVTON_BF16, IDMVTON_E_DTYPE, "softmax_rows: dtype %d", a->dtype);
-    CHECK_ARG(a->rows > 0 && a->n > 0 && a->n % 8 == 0 && a->ld % 8 == 0 && a->ld >= a->n && ((uintptr_t)a->x & 15) == 0,
+    CHECK_ARG(a->rows > 0 && a->n > 0 && a->n % 8 == 0 && (a->y_split || a->ld % 8 == 0) && a->ld >= a->n && ((uintptr_t)a->x & 15) == 0,
               IDMVTON_E_SHAPE, "softmax_rows: rows=%d n=%d ld=%d", a->rows, a->n, a->ld);
     const dim3 grid(a->rows), block(256);
+    if (a->y_split) {
+        CHECK_ARG(a->ldy % 8 == 0 && a->ldy >= 2 * a->n && ((uintptr_t)a->y_split & 15) == 0 && a->ld % 4 == 0, IDMVTON_E_SHAPE, "softmax_rows: y_split ldy=%d n=%d", a->ldy, a->n);
+        if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_split_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const float*)a->x, a->n, a->ld, a->scale, (bf16_t*)a->y_split, a->ldy);
+        else hipLaunchKernelGGL((softmax_rows_split_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (const float*)a->x, a->n, a->ld, a->scale, (f16_t*)a->y_split, a->ldy);
+        CHECK_LAUNCH("softmax_rows");
+        return IDMVTON_OK;
+    }
     if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)a->x, a->n, a->ld, a->scale);
     else hipLaunchKernelGGL((softmax_rows_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (f16_t*)a->x, a->n, a->ld, a->scale);
     CHECK_LAUNCH("softmax_rows");

@@ -12,8 +12,12 @@ LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_
 F16, BF16, F32, F8E4M3 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS = 0, 1
-IO_RES_F32, IO_OUT_F32 = 1, 2
-MAX_SEG = 12
+IO_RES_F32, IO_OUT_F32, IO_BIAS_F32 = 1, 2, 4
+GN_X_F32, GN_Y_SPLIT, GN_AFFINE_F32 = 1, 2, 4
+LAYOUT_SPLIT, LAYOUT_NHWC_F32 = 1, 2
+SPLIT_ACT, SPLIT_W3, SPLIT_W3T = 0, 1, 2
+MAX_SEG = 24
+ABI_VERSION = 6
 
 i32, u32, f32, vp = C.c_int32, C.c_uint32, C.c_float, C.c_void_p
 
@@ -45,7 +49,8 @@ class LayerNormArgs(C.Structure):
 
 class GroupNormArgs(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("HW", i32), ("C", i32), ("groups", i32), ("x", vp), ("C1", i32),
-                ("x2", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("silu", i32), ("y", vp), ("stats", vp), ("stats_doubles", i32)]
+                ("x2", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("silu", i32), ("y", vp), ("stats", vp), ("stats_doubles", i32),
+                ("flags", i32)]
 
 
 class PackInputArgs(C.Structure):
@@ -59,7 +64,7 @@ class CfgStepArgs(C.Structure):
 
 class LayoutArgs(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("C", i32), ("HW", i32), ("cpad", i32), ("to_nhwc", i32), ("src", vp),
-                ("dst", vp), ("scale", f32), ("shift", f32)]
+                ("dst", vp), ("scale", f32), ("shift", f32), ("flags", i32)]
 
 
 class VaeSampleArgs(C.Structure):
@@ -83,21 +88,26 @@ class QuantF8Args(C.Structure):
 
 
 class SoftmaxArgs(C.Structure):
-    _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32)]
+    _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32), ("y_split", vp), ("ldy", i32)]
+
+
+class SplitArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("mode", i32), ("rows", i32), ("cols", i32), ("src", vp), ("lds", i32), ("dst", vp), ("ldd", i32)]
 
 
 STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_attn_args": AttnArgs,
            "idmvton_layernorm_args": LayerNormArgs, "idmvton_groupnorm_args": GroupNormArgs,
            "idmvton_pack_input_args": PackInputArgs, "idmvton_cfg_step_args": CfgStepArgs,
            "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs, "idmvton_softmax_args": SoftmaxArgs,
-           "idmvton_attn_small_args": AttnSmallArgs, "idmvton_attn_f8_args": AttnF8Args, "idmvton_quant_f8_args": QuantF8Args}
+           "idmvton_attn_small_args": AttnSmallArgs, "idmvton_attn_f8_args": AttnF8Args, "idmvton_quant_f8_args": QuantF8Args,
+           "idmvton_split_args": SplitArgs}
 
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
            "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles",
            "idmvton_prefetch", "idmvton_attn_small", "idmvton_rccl_unique_id", "idmvton_rccl_comm_init", "idmvton_rccl_bcast_arena",
-           "idmvton_rccl_comm_destroy", "idmvton_attn_f8", "idmvton_quant_f8"]
+           "idmvton_rccl_comm_destroy", "idmvton_attn_f8", "idmvton_quant_f8", "idmvton_split"]
 
 _lib = None
 
@@ -120,13 +130,18 @@ def lib():
             raise HipLibraryMissing(f"{LIB_PATH} does not export {s}")
     L.idmvton_last_error.restype = C.c_char_p
     L.idmvton_sizeof.argtypes = [C.c_char_p]
+    L.idmvton_abi_version.restype = C.c_int
+    v = L.idmvton_abi_version()
+    if v != ABI_VERSION:                                  # semantic changes do not always move a struct size (v3 -> v5 did not): check the number too
+        raise HipLibraryMissing(f"{LIB_PATH} implements C ABI version {v}, this binding needs {ABI_VERSION}: rebuild it "
+                                f"(`make -C {os.path.join(_HERE, 'csrc')}`)")
     for name, st in STRUCTS.items():
         n = L.idmvton_sizeof(name.encode())
         if n != C.sizeof(st):
             raise HipLibraryMissing(f"ABI drift: sizeof({name}) is {n} in the library, {C.sizeof(st)} in ffi.py")
     for s in ("idmvton_gemm_conv", "idmvton_attn_fwd", "idmvton_layernorm", "idmvton_groupnorm",
               "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout", "idmvton_vae_sample", "idmvton_softmax_rows",
-              "idmvton_attn_small", "idmvton_attn_f8", "idmvton_quant_f8"):
+              "idmvton_attn_small", "idmvton_attn_f8", "idmvton_quant_f8", "idmvton_split"):
         getattr(L, s).argtypes = [vp, vp]
         getattr(L, s).restype = C.c_int
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]

@@ -121,7 +121,8 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     if out is None and n_out > 0:
         out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else w.dtype, device=w.device)
     a.io_flags = (ffi.IO_RES_F32 if res is not None and res.dtype == torch.float32 else 0) | \
-                 (ffi.IO_OUT_F32 if out is not None and out.dtype == torch.float32 else 0)
+                 (ffi.IO_OUT_F32 if out is not None and out.dtype == torch.float32 else 0) | \
+                 (ffi.IO_BIAS_F32 if bias is not None and bias.dtype == torch.float32 else 0)
     a.out = _ptr(out)
     a.ldo = (ldo if ldo is not None else (out.stride(-2) if out is not None else 0))
     a.bias = _ptr(bias)
@@ -302,19 +303,24 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, out2=None):
     return out
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu, stats, x2=None, out=None):
+def groupnorm(x, gamma, beta, groups, eps, silu, stats, x2=None, out=None, split_dtype=None):
     """x: [B][HW][C1] (+ optional x2 [B][HW][C2], virtually concatenated along C); stats: float64 scratch of at least
-    gn_stats_doubles(B, HW, C, groups) elements (GN_STATS_DOUBLES covers every shape with B <= 64, groups <= 32)."""
+    gn_stats_doubles(B, HW, C, groups) elements (GN_STATS_DOUBLES covers every shape with B <= 64, groups <= 32).
+    split_dtype (the split-precision VAE path): x, gamma, beta are float32 and the result is the pair [B][HW][2C] = [hi | lo] of that dtype."""
     B, HW, C1 = x.shape
     Cc = C1 + (x2.shape[-1] if x2 is not None else 0)
+    prec = split_dtype is not None
+    if prec and not (x.dtype == gamma.dtype == beta.dtype == torch.float32 and (x2 is None or x2.dtype == torch.float32)):
+        raise TypeError("groupnorm(split_dtype=...): x, gamma and beta must be float32")
     if out is None:
-        out = torch.empty((B, HW, Cc), dtype=x.dtype, device=x.device)
+        out = torch.empty((B, HW, 2 * Cc if prec else Cc), dtype=split_dtype if prec else x.dtype, device=x.device)
     a = ffi.GroupNormArgs()
-    a.dtype, a.B, a.HW, a.C, a.groups = _dt(x), B, HW, Cc, groups
+    a.dtype, a.B, a.HW, a.C, a.groups = _dt(out), B, HW, Cc, groups
+    a.flags = (ffi.GN_X_F32 | ffi.GN_Y_SPLIT | ffi.GN_AFFINE_F32) if prec else 0
     a.x, a.C1, a.x2 = _ptr(x), C1, _ptr(x2)
     a.gamma, a.beta, a.eps, a.silu = _ptr(gamma), _ptr(beta), eps, int(bool(silu))
     a.y, a.stats, a.stats_doubles = _ptr(out), _ptr(stats), stats.numel()
-    _call("idmvton_groupnorm", a, bytes_=3.0 * B * HW * Cc * x.element_size())
+    _call("idmvton_groupnorm", a, bytes_=(2.0 * x.element_size() + (2 if prec else 1) * out.element_size()) * B * HW * Cc)
     return out
 
 
@@ -344,13 +350,15 @@ def cfg_step(eps_nhwc, latents, noise, coef):
     return latents
 
 
-def to_nhwc(src_nchw_f32, dtype, cpad=None, scale=1.0, shift=0.0, out=None):
+def to_nhwc(src_nchw_f32, dtype, cpad=None, scale=1.0, shift=0.0, out=None, split=False):
+    """fp32 NCHW -> NHWC [cpad] of `dtype`; split=True: NHWC [2*cpad] = [hi | lo] (the split-precision VAE path)."""
     B, Cc = src_nchw_f32.shape[:2]
     HW = src_nchw_f32.numel() // (B * Cc)
     cpad = Cc if cpad is None else cpad
     if out is None:
-        out = torch.empty((B, HW, cpad), dtype=dtype, device=src_nchw_f32.device)
+        out = torch.empty((B, HW, 2 * cpad if split else cpad), dtype=dtype, device=src_nchw_f32.device)
     a = ffi.LayoutArgs()
+    a.flags = ffi.LAYOUT_SPLIT if split else 0
     a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = _dt(out), B, Cc, HW, cpad, 1
     a.src, a.dst, a.scale, a.shift = _ptr(src_nchw_f32), _ptr(out), scale, shift
     _call("idmvton_layout", a)
@@ -362,7 +370,9 @@ def to_nchw(src_nhwc, Cc, shape_hw, scale=1.0, shift=0.0, out=None):
     if out is None:
         out = torch.empty((B, Cc) + tuple(shape_hw), dtype=torch.float32, device=src_nhwc.device)
     a = ffi.LayoutArgs()
-    a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = _dt(src_nhwc), B, Cc, HW, cpad, 0
+    f32 = src_nhwc.dtype == torch.float32                  # the split-precision VAE path hands over an fp32 NHWC image
+    a.flags = ffi.LAYOUT_NHWC_F32 if f32 else 0
+    a.dtype, a.B, a.C, a.HW, a.cpad, a.to_nhwc = (ffi.BF16 if f32 else _dt(src_nhwc)), B, Cc, HW, cpad, 0
     a.src, a.dst, a.scale, a.shift = _ptr(src_nhwc), _ptr(out), scale, shift
     _call("idmvton_layout", a)
     return out
@@ -386,6 +396,30 @@ def softmax_rows(x, scale):
     a.x, a.scale = _ptr(x), scale
     _call("idmvton_softmax_rows", a)
     return x
+
+
+def softmax_rows_split(x, scale, dtype):
+    """softmax(scale * x) over the last dim of an fp32 2-D tensor -> the pair [rows][2n] = [hi | lo] of `dtype` (x is left as it is)."""
+    rows, n = x.shape
+    out = torch.empty((rows, 2 * n), dtype=dtype, device=x.device)
+    a = ffi.SoftmaxArgs()
+    a.dtype, a.rows, a.n, a.ld = _dt(out), rows, n, x.stride(0)
+    a.x, a.scale, a.y_split, a.ldy = _ptr(x), scale, _ptr(out), out.stride(0)
+    _call("idmvton_softmax_rows", a, bytes_=float(rows * n * (3 * 4 + 2 * out.element_size())))
+    return out
+
+
+def split(x, dtype, mode=ffi.SPLIT_ACT):
+    """fp32 [rows][cols] -> operand pairs of the split-precision GEMMs: SPLIT_ACT [rows][2 cols] = [hi | lo]; SPLIT_W3 [rows][3 cols] =
+    [hi | hi | lo]; SPLIT_W3T [cols][3 rows] = the W3 form of the transpose."""
+    rows, cols = x.shape
+    shape = {ffi.SPLIT_ACT: (rows, 2 * cols), ffi.SPLIT_W3: (rows, 3 * cols), ffi.SPLIT_W3T: (cols, 3 * rows)}[mode]
+    out = torch.empty(shape, dtype=dtype, device=x.device)
+    a = ffi.SplitArgs()
+    a.dtype, a.mode, a.rows, a.cols = _dt(out), mode, rows, cols
+    a.src, a.lds, a.dst, a.ldd = _ptr(x), x.stride(0), _ptr(out), out.stride(0)
+    _call("idmvton_split", a, bytes_=float(rows * cols * 4 + out.numel() * out.element_size()))
+    return out
 
 
 def prefetch(t, blocks=0, stream=None):

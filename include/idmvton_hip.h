@@ -51,7 +51,7 @@ int idmvton_sizeof(const char* struct_name); /* sizeof() of an args struct by na
  * Columns n >= vt_n0 (when vt != NULL) are written TRANSPOSED to vt[(b*(N-vt_n0) + n-vt_n0)*vt_tokens + tok] with
  * (b, tok) = divmod(m, vt_tokens): the V^T layout the attention kernel consumes.
  * ------------------------------------------------------------------------------------------------------------- */
-#define IDMVTON_MAX_SEG 12
+#define IDMVTON_MAX_SEG 24 /* 9 taps x {[hi|lo] pair, hi again} of the split-precision VAE convolutions + shortcut segments */
 typedef struct {
     const void* ptr; /* NHWC tensor base                           */
     uint32_t bytes;  /* size of that tensor in bytes (bounds check) */
@@ -63,7 +63,7 @@ typedef struct {
 
 enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1, IDMVTON_EPI_GELU = 2 /* gelu_erf(acc+bias+rowbias) then +res */,
        IDMVTON_EPI_QUICKGELU = 3 /* x*sigmoid(1.702x): CLIP-L text MLP (transformers hidden_act "quick_gelu") */ };
-enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2 };
+enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2, IDMVTON_IO_BIAS_F32 = 4 };
 typedef struct {
     int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type; see io_flags) */
     const void* w; int32_t N; int32_t Ktot;
@@ -90,7 +90,13 @@ typedef struct {
                                     fp32 elements).  The fp32 RESIDUAL STREAM of a Transformer2DModel: the block-to-block hidden state
                                     (src/attentionhacked_tryon.py:348,384,412: three `+ hidden_states` per block, 210 per TryonNet forward) is
                                     kept in fp32 between the to_out / ff.net.2 epilogues and the next LayerNorm instead of being rounded to
-                                    16 bits after every add; both need the 16-byte epilogue (all strides / N multiples of 8).  0 = off. */
+                                    16 bits after every add; both need the 16-byte epilogue (all strides / N multiples of 8).  0 = off.
+                                    IDMVTON_IO_BIAS_F32: `bias` holds fp32 (plain 16-byte epilogue only).  With all three, a GEMM whose operands are
+                                    bf16 [hi | lo] pairs (idmvton_split, idmvton_groupnorm's IDMVTON_GN_Y_SPLIT) carries fp32-equivalent values end
+                                    to end: the SPLIT-PRECISION path of the VAE, which the reference runs in fp32 (src/tryon_pipeline.py:1076-1093,
+                                    1868-1880 upcast_vae / force_upcast): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps 16 mantissa bits, and
+                                    x.w = hi.w_hi + lo.w_hi + hi.w_lo (+ O(2^-17)) is three K segments of ONE launch: activations [hi | lo] (K-segments
+                                    (coff 0, len 2C) and (coff 0, len C)) against weights laid out [w_hi | w_hi | w_lo]; two when w_lo == 0. */
     /* LayerNorm folded into the GEMMs on either side of it (src/attentionhacked_tryon.py:310,358,390: norm1/2/3 feed to_q|k|v, attn2.to_q,
        ff.net.0.proj).  LN(x).W^T = rstd[m] * (x . (gamma*W)^T)[m][n] - rstd[m]*mean[m]*s[n] + c[n],  s[n] = sum_k (gamma*W)[n][k],
        c[n] = sum_k beta[k] W[n][k]: the CONSUMER GEMM runs on the raw hidden state with gamma folded into its weights and applies the
@@ -227,13 +233,16 @@ int idmvton_layernorm(const idmvton_layernorm_args* a, void* stream);
  * `stats` is caller-owned scratch of idmvton_groupnorm_stats_doubles(B, HW, C, groups) doubles (its capacity goes in
  * `stats_doubles`); it needs no initialisation.
  * ------------------------------------------------------------------------------------------------------------- */
+enum { IDMVTON_GN_X_F32 = 1 /* x (and x2) hold fp32 */, IDMVTON_GN_Y_SPLIT = 2 /* y is [B][HW][2C] = [hi | lo], hi = dtype(v), lo = dtype(v - hi) */,
+       IDMVTON_GN_AFFINE_F32 = 4 /* gamma / beta hold fp32 */ };
 typedef struct {
     int32_t dtype; int32_t B, HW, C, groups;
     const void* x; int32_t C1;  /* channels taken from x  (== C when x2 is NULL) */
     const void* x2;
     const void* gamma; const void* beta; float eps; int32_t silu;
-    void* y;                    /* [B][HW][C] */
+    void* y;                    /* [B][HW][C]  ([B][HW][2C] with IDMVTON_GN_Y_SPLIT) */
     double* stats; int32_t stats_doubles;
+    int32_t flags;              /* IDMVTON_GN_*: the split-precision VAE path (see idmvton_gemm_conv_args.io_flags); 0 = the 16-bit form */
 } idmvton_groupnorm_args;
 int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream);
 int idmvton_groupnorm_stats_doubles(int B, int HW, int C, int groups);
@@ -259,9 +268,11 @@ typedef struct {
 int idmvton_cfg_step(const idmvton_cfg_step_args* a, void* stream);
 
 /* Layout / dtype conversion at the pipeline edges: NCHW fp32 <-> NHWC dtype with channel padding. */
+enum { IDMVTON_LAYOUT_SPLIT = 1 /* to_nhwc: dst is NHWC [2*cpad] = [hi | lo] */, IDMVTON_LAYOUT_NHWC_F32 = 2 /* to_nchw: src NHWC holds fp32 */ };
 typedef struct {
     int32_t dtype; int32_t B, C, HW, cpad; int32_t to_nhwc; /* 1: src fp32 NCHW -> dst dtype NHWC[cpad]; 0: reverse */
     const void* src; void* dst; float scale; float shift;    /* dst = src*scale + shift */
+    int32_t flags;                                           /* IDMVTON_LAYOUT_*: edges of the split-precision VAE path */
 } idmvton_layout_args;
 int idmvton_layout(const idmvton_layout_args* a, void* stream);
 
@@ -279,8 +290,26 @@ int idmvton_vae_sample(const idmvton_vae_sample_args* a, void* stream);
 typedef struct {
     int32_t dtype; int32_t rows, n, ld;
     void* x; float scale;
+    void* y_split; int32_t ldy;  /* NULL: in place, x of `dtype`.  Else x holds fp32 [rows][ld] (read only) and the probabilities are written as the
+                                    pair [rows][ldy] = [hi (n) | lo (n)] of `dtype`: the A operand of the split-precision P.V product */
 } idmvton_softmax_args;
 int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * idmvton_split : fp32 -> bf16 / fp16 [hi | lo] pairs, the operands of the split-precision GEMMs (idmvton_gemm_conv_args.io_flags).
+ * The reference keeps these tensors in fp32 (upcast VAE: src/tryon_pipeline.py:1076-1093,1868-1880); here a value x travels as
+ * hi = dtype(x), lo = dtype(x - hi).  src: fp32 [rows][cols], row stride lds (elements).
+ *   mode IDMVTON_SPLIT_ACT : dst [rows][ldd] = [hi (cols) | lo (cols)]                       (activation side: K-segments 2C + C)
+ *   mode IDMVTON_SPLIT_W3  : dst [rows][ldd] = [hi | hi | lo]                                (weight side of an activation x activation product)
+ *   mode IDMVTON_SPLIT_W3T : dst [cols][ldd] = the W3 form of src^T (V^T of the VAE mid-block attention), ldd >= 3*rows
+ * ------------------------------------------------------------------------------------------------------------- */
+enum { IDMVTON_SPLIT_ACT = 0, IDMVTON_SPLIT_W3 = 1, IDMVTON_SPLIT_W3T = 2 };
+typedef struct {
+    int32_t dtype; int32_t mode; int32_t rows, cols;
+    const float* src; int32_t lds;
+    void* dst; int32_t ldd;
+} idmvton_split_args;
+int idmvton_split(const idmvton_split_args* a, void* stream);
 
 /* Weight prefetch: touches one dword per 128-byte line of [ptr, ptr+bytes) from `blocks` workgroups (0 = 64) so the range is
  * resident in the Infinity Cache / L2 when its consumer starts.  No result; run it on a side stream ahead of the consumer.

@@ -543,6 +543,117 @@ def check_groupnorm_reproducible(B, HW, Cc, dtype, dev, groups=32):
     return 0.0 if all(torch.equal(outs[0], o) for o in outs[1:]) else 1.0
 
 
+# ------------------------------------------------------------------------------------------------ split-precision (fp32-equivalent) VAE path
+def _relerr64(x, ref):
+    x, ref = x.detach().double().cpu(), ref.detach().double().cpu()
+    if not torch.isfinite(x).all():
+        return float("inf")
+    return ((x - ref).abs().max() / ref.abs().max().clamp_min(1e-300)).item()
+
+
+def check_split(rows, cols, dev, mode, seed=0):
+    """idmvton_split: hi = bf16(x), lo = bf16(x - hi) bit for bit, in the layout of each mode; hi + lo reproduces x to 2^-16."""
+    from idm_vton_amd import ffi, ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(rows, cols, generator=g) * torch.exp(4 * torch.randn(rows, 1, generator=g))).to(dev)      # rows spread over ~10 binades
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    out = ops.split(x, torch.bfloat16, mode)
+    if mode == ffi.SPLIT_ACT:
+        ref = torch.cat([hi, lo], 1)
+    elif mode == ffi.SPLIT_W3:
+        ref = torch.cat([hi, hi, lo], 1)
+    else:
+        ref = torch.cat([hi.t(), hi.t(), lo.t()], 1).contiguous()
+    exact = 0.0 if torch.equal(out.view(torch.int16), ref.view(torch.int16)) else 1.0
+    return max(exact, _relerr64(hi.double() + lo.double(), x) / 256.0)            # second term: <= 2^-16 -> contributes <= 6e-8
+
+
+def check_gn_precise(B, HW, Cc, dev, groups=32, silu=True, seed=0):
+    """GroupNorm in the split-precision form: fp32 in, fp32 affine, [hi | lo] out; hi + lo against an fp64 reference."""
+    from idm_vton_amd import ops
+    x = _r(B, HW, Cc, dtype=torch.float32, dev=dev, scale=2.0, seed=seed) * 37.0 + 11.0
+    g = _r(Cc, dtype=torch.float32, dev=dev, seed=seed + 1)
+    b = _r(Cc, dtype=torch.float32, dev=dev, seed=seed + 2)
+    ref = F.group_norm(x.double().transpose(1, 2), groups, g.double(), b.double(), 1e-6).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    stats = torch.empty(ops.gn_stats_doubles(B, HW, Cc, groups), dtype=torch.float64, device=dev)
+    out = ops.groupnorm(x, g, b, groups, 1e-6, silu, stats, split_dtype=torch.bfloat16)
+    assert out.shape == (B, HW, 2 * Cc)
+    return _relerr64(out[..., :Cc].double() + out[..., Cc:].double(), ref)
+
+
+def check_softmax_split(rows, n, dev, seed=0):
+    from idm_vton_amd import ops
+    x = _r(rows, n, dtype=torch.float32, dev=dev, scale=3.0, seed=seed)
+    keep = x.clone()
+    out = ops.softmax_rows_split(x, 0.7, torch.bfloat16)
+    ref = torch.softmax(0.7 * x.double(), dim=-1)
+    assert torch.equal(x, keep)
+    return _relerr64(out[:, :n].double() + out[:, n:].double(), ref)
+
+
+def check_plin(M, N, K, dev, exact_w=False, res=True, seed=0):
+    """A Linear through the split-precision path (vae._PConv: [hi | lo] activations x [w_hi | w_hi][w_lo] weights, fp32 bias / residual /
+    output) against fp64: fp32-equivalent (<= 2e-5 of the output range), where the 16-bit path gives 2e-3 / 1.6e-2."""
+    from idm_vton_amd import ops
+    from idm_vton_amd.vae import _PConv
+    x = _r(M, K, dtype=torch.float32, dev=dev, seed=seed)
+    w = _r(N, K, dtype=torch.float32, dev=dev, scale=K ** -0.5, seed=seed + 1)
+    if exact_w:
+        w = w.to(torch.bfloat16).float()
+    b = _r(N, dtype=torch.float32, dev=dev, seed=seed + 2)
+    rs = _r(M, N, dtype=torch.float32, dev=dev, seed=seed + 3) if res else None
+    cv = _PConv(w, b)
+    assert cv.three == (not exact_w)
+    xp = ops.split(x, torch.bfloat16)
+    out = ops.gemm_conv(cv.segs(xp, 0), cv.w, M, bias=cv.b, res=rs, out_f32=True)
+    ref = x.double() @ w.double().t() + b.double() + (rs.double() if res else 0.0)
+    return _relerr64(out, ref)
+
+
+def check_pconv(B, Cin, Cout, H, W, dev, ups=False, shortcut=0, exact_w=False, seed=0):
+    """3x3 conv (optionally fused nearest-2x, optionally a fused 1x1 shortcut on a second input) through the split-precision path vs fp64."""
+    from idm_vton_amd import ops
+    from idm_vton_amd.vae import _PConv
+    x = _r(B, H, W, Cin, dtype=torch.float32, dev=dev, seed=seed)
+    w = _r(Cout, Cin, 3, 3, dtype=torch.float32, dev=dev, scale=(9 * Cin) ** -0.5, seed=seed + 1)
+    b = _r(Cout, dtype=torch.float32, dev=dev, seed=seed + 2)
+    q = (lambda t: t.to(torch.bfloat16).float()) if exact_w else (lambda t: t)
+    w = q(w)
+    xin = x.double().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+    sc, xs = None, None
+    if shortcut:
+        x2 = _r(B, H, W, shortcut, dtype=torch.float32, dev=dev, seed=seed + 3)
+        ws = q(_r(Cout, shortcut, 1, 1, dtype=torch.float32, dev=dev, scale=shortcut ** -0.5, seed=seed + 4))
+        bs = _r(Cout, dtype=torch.float32, dev=dev, seed=seed + 5)
+        ref = ref + F.conv2d(x2.double().permute(0, 3, 1, 2), ws.double(), bs.double())
+        sc = (ws, bs)
+        xs = ops.split(x2.reshape(-1, shortcut), torch.bfloat16).view(B, H * W, 2 * shortcut)
+    cv = _PConv(w, b, shortcut=sc)
+    xp = ops.split(x.reshape(-1, Cin), torch.bfloat16).view(B, H * W, 2 * Cin)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    out = ops.gemm_conv(cv.segs(xp, 1, xs), cv.w, B * Ho * Wo, Ho=Ho, Wo=Wo, Hi=H, Wi=W, ups=ups, bias=cv.b, out_f32=True)
+    return _relerr64(out.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref)
+
+
+def check_layout_split(B, h, w, dev, seed=0):
+    from idm_vton_amd import ops
+    src = _r(B, 4, h, w, dtype=torch.float32, dev=dev, seed=seed) * 5.0
+    n = ops.to_nhwc(src, torch.bfloat16, cpad=64, scale=2.0, shift=-1.0, split=True)                     # [B][hw][128]
+    v = (src * 2.0 - 1.0).permute(0, 2, 3, 1).reshape(B, h * w, 4)
+    e1 = _relerr64(n[..., :4].double() + n[..., 64:68].double(), v)
+    e2 = float(n[..., 4:64].abs().max() + n[..., 68:].abs().max())
+    img = _r(B, h * w, 8, dtype=torch.float32, dev=dev, seed=seed + 1)
+    back = ops.to_nchw(img, 3, (h, w), scale=0.5, shift=0.5)
+    e3 = _relerr64(back, (img[..., :3] * 0.5 + 0.5).reshape(B, h, w, 3).permute(0, 3, 1, 2))
+    return max(e1, e2, e3)
+
+
 def check_elementwise(B, h, w, dtype, dev, seed=0):
     from idm_vton_amd import ops
     hw = h * w
@@ -578,7 +689,7 @@ def _hint(variant, bn, bm):
     return (variant << 28) | (bn << 16) | bm
 
 
-RING_TILES = ((_hint(4, 256, 256), "h4f0"), (_hint(4, 256, 257), "h4f1"), (_hint(4, 256, 258), "h4f2"), (_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
+RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"), (_hint(5, 256, 258), "h5f2"), (_hint(5, 256, 259), "h5f3"), (_hint(5, 256, 260), "h5f4"),
               (_hint(3, 256, 256), "q256x256"), (_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))
@@ -735,4 +846,22 @@ def all_checks(dev="cuda"):
         add("groupnorm_reproducible_320", lambda dt=dt: check_groupnorm_reproducible(4, 12288, 320, dt, dev), 0.0)
         add("groupnorm_reproducible_2560", lambda dt=dt: check_groupnorm_reproducible(2, 768, 2560, dt, dev), 0.0)
         add("elementwise", lambda dt=dt: check_elementwise(2, 16, 12, dt, dev))
+    # the split-precision (fp32-equivalent) path of the VAE decode: operand pairs are bf16 whatever the engine's storage type.  Bars: a
+    # 3-term product carries ~2^-16 per operand (measured ~3e-6 of the output range); the 16-bit path sits at 2e-3 (fp16) / 1.6e-2 (bf16)
+    from idm_vton_amd import ffi
+    P = lambda name, fn, t: out.append((f"{name}[split]", fn, t))
+    for mode, tag in ((ffi.SPLIT_ACT, "act"), (ffi.SPLIT_W3, "w3"), (ffi.SPLIT_W3T, "w3t")):
+        P(f"split_{tag}_768x512", lambda mode=mode: check_split(768, 512, dev, mode), 1e-7)
+        P(f"split_{tag}_ragged_200x72", lambda mode=mode: check_split(200, 72, dev, mode), 1e-7)
+    P("gn_precise_512_silu", lambda: check_gn_precise(2, 768, 512, dev), 2e-5)
+    P("gn_precise_128_nosilu", lambda: check_gn_precise(1, 4096, 128, dev, silu=False), 2e-5)
+    P("softmax_split_64x3072", lambda: check_softmax_split(64, 3072, dev), 2e-5)
+    P("plin_768x512x512_3term", lambda: check_plin(768, 512, 512, dev), 2e-5)
+    P("plin_768x512x512_exact_weights_2term", lambda: check_plin(768, 512, 512, dev, exact_w=True), 2e-5)
+    P("plin_ragged_1000x64x128", lambda: check_plin(1000, 64, 128, dev, res=False), 2e-5)
+    P("pconv_128_to_128_16x12", lambda: check_pconv(2, 128, 128, 16, 12, dev), 2e-5)
+    P("pconv_256_to_128_shortcut", lambda: check_pconv(1, 128, 128, 16, 12, dev, shortcut=256), 2e-5)
+    P("pconv_ups_128", lambda: check_pconv(2, 128, 128, 9, 7, dev, ups=True), 2e-5)
+    P("pconv_exact_weights_shortcut", lambda: check_pconv(1, 128, 64, 8, 8, dev, shortcut=128, exact_w=True), 2e-5)
+    P("layout_split_and_f32_nhwc", lambda: check_layout_split(2, 16, 12, dev), 2e-5)
     return out

@@ -1,4 +1,4 @@
-"""Round 4: the hand-scheduled 256x256 Linear main loop (csrc/gemm_lin.hip, tile_hint variants 4 / 5) against the compiler-scheduled
+"""Round 4: the hand-scheduled 256x256 Linear main loop (csrc/gemm_lin.hip, tile_hint variant 5, placement forms 0-4) against the compiler-scheduled
 256x256 / 128x256 tiles and hipBLASLt (torch.matmul: measurement only) on the loop's real large-GEMM shapes.  Interleaved rounds in ONE
 process (guide rule 24), random operands (rule 25); every variant's output is compared with the 8-wave ring tile's (same k order and MFMA:
 expected bit-identical).  cold = behind a 640 MB flush (weights from HBM, as in the loop); warm = 10 back-to-back launches.
@@ -19,8 +19,8 @@ def hint(v, bn, bm):
     return (v << 28) | (bn << 16) | bm
 
 
-VARIANTS = [("r256x256", hint(1, 256, 256)), ("r128x256", hint(1, 128, 256)), ("h4f0", hint(4, 256, 256)), ("h4f1", hint(4, 256, 257)),
-            ("h4f2", hint(4, 256, 258)), ("h5f0", hint(5, 256, 256)), ("h5f1", hint(5, 256, 257))]
+VARIANTS = [("r256x256", hint(1, 256, 256)), ("r128x256", hint(1, 128, 256)), ("h5f0", hint(5, 256, 256)), ("h5f1", hint(5, 256, 257)),
+            ("h5f2", hint(5, 256, 258)), ("h5f3", hint(5, 256, 259)), ("h5f4", hint(5, 256, 260))]
 
 
 def main():
@@ -59,6 +59,12 @@ def main():
                       lambda x4=x4, w4=w4: torch.matmul(x4, w4.t())))
     x2, w5, b5 = r(3072, 1280), r(3840, 1280, scale=0.03), r(3840)
     cases.append(("plain 3072x3840x1280 (QKV shape, no V^T)", 2.0 * 3072 * 3840 * 1280, lambda h: ops.linear(x2, w5, bias=b5, tile_hint=h), lambda: torch.matmul(x2, w5.t())))
+    qk_o, vt_o = torch.empty(3072, 2560, dtype=dt, device=dev), torch.empty(4, 1280, 768, dtype=dt, device=dev)
+
+    def qkv(h):                                                  # fused QKV of a TryonNet level-2 block: q | k plain, v transposed in key order
+        ops.linear(x2, w5, out=qk_o, vt=vt_o, vt_n0=2560, vt_tokens=768, colscale_n=1280, colscale=ops.QSCALE, tile_hint=h)
+        return torch.cat([qk_o.reshape(-1), vt_o.reshape(-1)])
+    cases.append(("qkv 3072x3840x1280 with V^T (TryonNet L2)", 2.0 * 3072 * 3840 * 1280, qkv, lambda: torch.matmul(x2, w5.t())))
     x3, w6, r6 = r(9216, 1280), r(1280, 1280, scale=0.03), r(9216, 1280)
     cases.append(("proj 9216x1280x1280 + res", 2.0 * 9216 * 1280 * 1280, lambda h: ops.linear(x3, w6, res=r6, tile_hint=h), lambda: torch.matmul(x3, w6.t())))
     if not quick:
