@@ -412,15 +412,16 @@ class StableDiffusionXLInpaintPipeline:
             steps_noise = torch.stack([_randn(shape, generator, device, eng.dtype) for _ in range(n_exec)])
         image_states = self.prepare_ip_adapter_image_embeds(ip_adapter_image, device, 1)        # :1720-1723
 
-        lat = eng(image=img, mask_image=msk, pose_img=pose, cloth=clo, prompt_embeds=prompt_embeds,
-                  negative_prompt_embeds=negative_prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
-                  negative_pooled_prompt_embeds=negative_pooled_prompt_embeds, text_embeds_cloth=text_embeds_cloth,
-                  noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=steps_noise, image=n_img,
-                             latents_given=latents is not None),
-                  num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, ip_hidden_states=image_states,
-                  strength=strength, image_dtype=prompt_embeds.dtype,
-                  scheduler=kind, height=height, width=width, return_latents=True, use_graph=self.use_graph,
-                  overlap=self.overlap)
+        call = dict(image=img, mask_image=msk, pose_img=pose, cloth=clo, prompt_embeds=prompt_embeds,
+                    negative_prompt_embeds=negative_prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+                    negative_pooled_prompt_embeds=negative_pooled_prompt_embeds, text_embeds_cloth=text_embeds_cloth,
+                    noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=steps_noise, image=n_img,
+                               latents_given=latents is not None),
+                    num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, ip_hidden_states=image_states,
+                    strength=strength, scheduler=kind, height=height, width=width)
+        if isinstance(getattr(self, "trace_call", None), dict):    # test hook: what crossed the engine boundary (an oracle can replay it)
+            self.trace_call.update(call)
+        lat = eng(image_dtype=prompt_embeds.dtype, return_latents=True, use_graph=self.use_graph, overlap=self.overlap, **call)
         if output_type == "latent":
             return (lat.clone(),)
         out = eng.decode(lat)                                                                    # :1876 + postprocess

@@ -23,6 +23,9 @@
 // weight's, so issuing a tile costs one add per DMA instead of the ~12 VALU of the conv gather.
 #include <cstdlib>
 #include <type_traits>
+#if !defined(__gfx950__) && !defined(__gfx942__) && defined(__HIP_DEVICE_COMPILE__)
+#error "gemm_conv.hip: the in-launch LayerNorm hand-off and the counted vmcnt pipeline are written for gfx94x/gfx950 (stores counted in vmcnt)"
+#endif
 #include "common.cuh"
 
 #include "gemm_common.cuh"
@@ -261,7 +264,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         const int tid = threadIdx.x;
         uint32_t* cnt = p.rs_counter + m0 / BM;
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // acq_rel at agent scope: a release for this tile's partials (already written through and drained above; the fence makes
+            // that a property of the memory model instead of the gfx9 vmcnt counting stores) and an acquire for the last arriver
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             *flag = old + 1u == (unsigned)p.tiles_n ? 1u : 0u;
         }
         __syncthreads();
@@ -285,15 +290,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
             scr[(part * BM + r) * 2] = s1; scr[(part * BM + r) * 2 + 1] = s2;
             __syncthreads();
             if (tid < BM && m0 + tid < p.M) {
-                float a1 = 0.f, a2 = 0.f;
+                double a1 = 0.0, a2 = 0.0;                    // E[x^2] - mean^2 cancels in fp32 on rows with a large mean: fold in double
 #pragma unroll
-                for (int q = 0; q < TPR; ++q) { a1 += scr[(q * BM + tid) * 2]; a2 += scr[(q * BM + tid) * 2 + 1]; }
-                const float invc = 1.0f / (float)(P * 32);
-                const float mean = a1 * invc;
-                float var = a2 * invc - mean * mean;
-                var = var > 0.f ? var : 0.f;
-                const float rstd = rsqrtf(var + p.rs_eps);
-                *(float2*)(p.rs_final + (size_t)(m0 + tid) * 2) = make_float2(rstd, -rstd * mean);   // read by the NEXT launch: plain store
+                for (int q = 0; q < TPR; ++q) { a1 += (double)scr[(q * BM + tid) * 2]; a2 += (double)scr[(q * BM + tid) * 2 + 1]; }
+                const double invc = 1.0 / (double)(P * 32);
+                const double mean = a1 * invc;
+                double var = a2 * invc - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)p.rs_eps));
+                *(float2*)(p.rs_final + (size_t)(m0 + tid) * 2) = make_float2(rstd, (float)(-(double)rstd * mean));   // read by the NEXT launch: plain store
             }
             if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

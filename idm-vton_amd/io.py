@@ -63,10 +63,16 @@ def shard_dataloaders(rank, world):
 
 
 def _to_uint8_hwc(t):
-    """CxHxW (or 1xCxHxW) float in [0, 1] -> HxWxC uint8 tensor; the rounding of torchvision.utils.save_image (x*255 + 0.5, clamp)."""
+    """CxHxW (or 1xCxHxW) float in [0, 1] -> HxWxC uint8 tensor; the rounding of torchvision.utils.save_image (x*255 + 0.5, clamp).
+    torchvision writes a GRID for a batch of N > 1 images; the try-on scripts save one image per call (inference.py:417-419), and a
+    silent `t[0]` would drop N - 1 results, so a real batch is an error here."""
     t = t.detach()
     if t.ndim == 4:
+        if t.shape[0] != 1:
+            raise ValueError(f"save_image: a batch of {t.shape[0]} images (torchvision would write a grid); pass one CxHxW image per call")
         t = t[0]
+    if t.ndim != 3:
+        raise ValueError(f"save_image: expected CxHxW, got shape {tuple(t.shape)}")
     return t.float().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)
 
 
@@ -143,6 +149,30 @@ def default_writer():
     return _writer
 
 
-def save_image_async(tensor, fp, **kwargs):
-    """Drop-in for torchvision.utils.save_image(single image, path): same bytes on disk, written in the background."""
-    default_writer().submit(tensor, fp, **kwargs)
+def save_image_async(tensor, fp, format=None, **kwargs):
+    """Drop-in for torchvision.utils.save_image(single image, path): same bytes on disk, written in the background.  torchvision's grid /
+    normalisation keywords (nrow, padding, normalize, value_range, scale_each, pad_value) mean something else to PIL.Image.save: they are
+    accepted only at the values that leave a single image untouched."""
+    neutral = dict(nrow=8, padding=2, normalize=False, value_range=None, scale_each=False, pad_value=0.0)
+    for k, v in kwargs.items():
+        if k not in neutral:
+            raise TypeError(f"save_image: unknown keyword {k!r}")
+        if k in ("normalize", "scale_each", "value_range") and v not in (False, None):
+            raise NotImplementedError(f"save_image({k}={v!r}) is not supported by the asynchronous writer")
+    default_writer().submit(tensor, fp, **({"format": format} if format else {}))
+
+
+def flush_or_die():
+    """Join the default writer; on a write error print it and end the process with a non-zero status (an atexit hook cannot change
+    the exit code, and images lost behind a zero status are the worst outcome for a batch job)."""
+    if _writer is None:
+        return
+    try:
+        _writer.flush()
+    except Exception as e:                                 # noqa: BLE001
+        import sys
+        import traceback
+        traceback.print_exception(type(e), e, e.__traceback__)
+        sys.stdout.flush()                                 # os._exit skips the interpreter's own flush of buffered output
+        sys.stderr.flush()
+        os._exit(1)

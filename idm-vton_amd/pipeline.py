@@ -353,7 +353,20 @@ class TryonEngine:
         return (img / 2 + 0.5).clamp(0, 1)                                                 # postprocess
 
     @torch.no_grad()
-    def __call__(self, *, return_latents=False, use_graph=False, overlap=False, **kw):
+    def __call__(self, *, return_latents=False, use_graph=False, overlap=False, timing=None, **kw):
+        """timing: a list that receives one (start, prepared, denoised, decoded) tuple of HIP events recorded on the current stream
+        (bench.py: the loop's share of a timed call without a second, instrumented run)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timing is not None else None
+        if ev:
+            ev[0].record()
         st = self.prepare(**kw)
+        if ev:
+            ev[1].record()
         lat = self.denoise(st, use_graph=use_graph, overlap=overlap)
-        return lat if return_latents else self.decode(lat)
+        if ev:
+            ev[2].record()
+        out = lat if return_latents else self.decode(lat)
+        if ev:
+            ev[3].record()
+            timing.append(tuple(ev))
+        return out

@@ -296,16 +296,22 @@ class HipVAE:
         k = self._plin(t, p + ".to_k")
         v = self._plin(t, p + ".to_v")
         o = torch.empty(B * N, C, dtype=torch.float32, device=self.device)
+        # query rows in chunks: the probability pair [rows][2N] is addressed through a 32-bit buffer descriptor (< 2 GiB): all 12288 rows at
+        # once at 768x1024, 16384 of the 24576 at 1024x1536
+        qc = max(256, min(N, (2 ** 31 - 1) // (4 * N) // 256 * 256))
         for b in range(B):
-            sl = slice(b * N, (b + 1) * N)
-            qp = self._pair(q[sl])
-            k3 = ops.split(k[sl], self.PDT, ffi.SPLIT_W3)
-            s = ops.gemm_conv([ops.SegSpec(qp, 0, 2 * C), ops.SegSpec(qp, 0, C)], k3, N, out_f32=True)          # [N][N] logits, 3-term product
-            pp = ops.softmax_rows_split(s, 1.0, self.PDT)
-            del s
-            vt3 = ops.split(v[sl], self.PDT, ffi.SPLIT_W3T)                                                     # [C][3N]
-            ops.gemm_conv([ops.SegSpec(pp, 0, 2 * N), ops.SegSpec(pp, 0, N)], vt3, N, out=o[sl])
-            del pp, vt3
+            k3 = ops.split(k[b * N:(b + 1) * N], self.PDT, ffi.SPLIT_W3)
+            vt3 = ops.split(v[b * N:(b + 1) * N], self.PDT, ffi.SPLIT_W3T)                                      # [C][3N]
+            for r0 in range(0, N, qc):
+                sl = slice(b * N + r0, b * N + min(r0 + qc, N))
+                n = sl.stop - sl.start
+                qp = self._pair(q[sl])
+                s = ops.gemm_conv([ops.SegSpec(qp, 0, 2 * C), ops.SegSpec(qp, 0, C)], k3, n, out_f32=True)      # [n][N] logits, 3-term product
+                pp = ops.softmax_rows_split(s, 1.0, self.PDT)
+                del s
+                ops.gemm_conv([ops.SegSpec(pp, 0, 2 * N), ops.SegSpec(pp, 0, N)], vt3, n, out=o[sl])
+                del pp
+            del k3, vt3
         out = self._plin(self._pair(o), p + ".to_out.0", res=x.reshape(B * N, C))
         return out.view(B, N, C)
 

@@ -9,7 +9,7 @@ def save_image(tensor, fp, **kwargs):
     import os
     if os.environ.get("IDMVTON_ASYNC_SAVE") == "1":
         from idm_vton_amd.io import save_image_async
-        return save_image_async(tensor, fp)
+        return save_image_async(tensor, fp, **kwargs)
     from PIL import Image
     t = tensor.detach().float().cpu()
     if t.ndim == 4:

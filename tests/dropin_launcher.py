@@ -75,7 +75,10 @@ def main():
     pio.shard_dataloaders(rank, world)
     os.environ.setdefault("IDMVTON_ASYNC_SAVE", "1")
     sys.argv = [script] + sys.argv[2:]
-    runpy.run_path(script, run_name="__main__")
+    try:
+        runpy.run_path(script, run_name="__main__")
+    finally:
+        pio.flush_or_die()                               # queued images reach the disk, or the process ends non-zero (never both lost and 0)
 
 
 if __name__ == "__main__":

@@ -11,8 +11,13 @@ tolerance"; the tolerance is MEASURED here as the `ref_fp16` leg -- the oracle r
   * bf16 product  <= BF16_FACTOR x ref_fp16   (bf16 storage has 3 fewer mantissa bits than fp16: unit roundoff x 8, times 1.5 because the
                                                max over ~1e5 elements is a noisy statistic -- the ref_fp16 leg itself moved between 1.76e-3
                                                and 2.2e-3 on the 2-step stage from one box to the next; measured ratios: 1.2 .. 8.8);
-  * the VAE stages have no reduced-precision reference policy (the reference upcasts its VAE to fp32) and keep absolute bars:
-    one 16-bit rounding of each of ~60 chained feature maps.
+  * the VAE stages have no reduced-precision reference policy: the reference upcasts its VAE to fp32 (tryon_pipeline.py:1076-1093,
+    1868-1880).  DECODE runs the split-precision path (idm_vton_amd/vae.py: bf16 [hi | lo] operand pairs, fp32 everywhere between two
+    GEMMs) on every engine: absolute bar 3e-4 of the image range (measured 1.9e-5 / 2.9e-5, profiles/r04_vae_split_decode_v1.json; the
+    16-bit decode it replaces sat at 2.2e-3 fp16 / 1.8e-2 bf16).  ENCODE keeps 16-bit storage (one rounding of each of ~30 chained
+    feature maps, measured 1.2e-4 fp16 / 9.6e-4 bf16 -- below the north star's 1e-3 on the latents it produces): bars 5e-4 / 3e-3.
+  * the 30-step operating point of the benchmark additionally carries an ABSOLUTE bf16 bar: <= 1.5 x ref_fp16 (measured 1.2 x), so a
+    regression of the headline dtype cannot hide inside the 12 x stage factor.
 """
 import os
 
@@ -22,7 +27,8 @@ import torch
 pytestmark = pytest.mark.gpu
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_parity.json")
 FP16_FACTOR, BF16_FACTOR = 1.25, 12.0
-VAE_BARS = {"hip_f16": 5e-3, "hip_bf16": 4e-2}
+VAE_BARS = {"cfg2_vae_decode": {"hip_f16": 3e-4, "hip_bf16": 3e-4}, "cfg2_vae_encode_sample": {"hip_f16": 5e-4, "hip_bf16": 3e-3}}
+BF16_30STEP_FACTOR = 1.5
 ANCHOR_BAR = 5e-5                   # fp32 summation order, 140 chained blocks
 DEFAULT_LEGS = ("hip_bf16", "hip_f16")
 
@@ -83,13 +89,16 @@ def test_config2_all_30_ddim_steps(world):
     """The whole operating point of the benchmark: 30 DDIM steps, latents against the oracle at steps 1, 10, 20, 30."""
     _run(world, "cfg2_30steps")
     _check(world, "cfg2_b1_ddim30_latents")
+    r = world.results["cfg2_b1_ddim30_latents"]
+    bar = BF16_30STEP_FACTOR * r["ref_fp16"]["rel"]
+    assert r["hip_bf16"]["rel"] <= bar, f"bf16 after 30 DDIM steps: {r['hip_bf16']['rel']:.3e} > {bar:.3e} (= {BF16_30STEP_FACTOR} x the reference's fp16 policy)"
 
 
 def test_config2_vae_decode_and_encode(world):
     _run(world, "vae")
-    for stage in ("cfg2_vae_decode", "cfg2_vae_encode_sample"):
-        for leg, bar in VAE_BARS.items():
-            assert world.results[stage][leg]["rel"] <= bar, (stage, leg, world.results[stage][leg])
+    for stage, bars in VAE_BARS.items():
+        for leg, bar in bars.items():
+            assert world.results[stage][leg]["rel"] <= bar, (stage, leg, world.results[stage][leg], bar)
 
 
 def test_config4_garmentnet_features_and_tryonnet_eps(world):

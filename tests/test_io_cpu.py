@@ -70,3 +70,33 @@ def test_async_writer_reports_errors_on_flush(tmp_path):
     w.submit(torch.rand(3, 8, 8), str(tmp_path / "ok.jpg"))
     w.close()
     assert os.path.getsize(tmp_path / "ok.jpg") > 0
+
+
+def test_save_image_async_rejects_what_it_would_silently_get_wrong(tmp_path):
+    """a batch of N > 1 images (torchvision writes a grid; dropping N - 1 of them silently is the worst outcome) and
+    torchvision keywords that mean something else to PIL are errors, not guesses."""
+    import pytest
+    import torch
+    from idm_vton_amd import io as pio
+    with pytest.raises(ValueError, match="batch of 2"):
+        pio.save_image_async(torch.rand(2, 3, 8, 8), str(tmp_path / "a.png"))
+    with pytest.raises(TypeError, match="quality_level"):
+        pio.save_image_async(torch.rand(3, 8, 8), str(tmp_path / "b.png"), quality_level=3)
+    with pytest.raises(NotImplementedError, match="normalize"):
+        pio.save_image_async(torch.rand(3, 8, 8), str(tmp_path / "c.png"), normalize=True)
+    pio.save_image_async(torch.rand(1, 3, 8, 8), str(tmp_path / "d.png"), nrow=8, padding=2)     # neutral grid keywords: fine
+    pio.default_writer().flush()
+    assert (tmp_path / "d.png").exists()
+
+
+def test_launcher_exits_nonzero_when_a_queued_image_cannot_be_written(tmp_path):
+    """write errors of the asynchronous writer used to surface in an atexit hook (printed, exit status 0)."""
+    import subprocess
+    import sys
+    script = tmp_path / "s.py"
+    (tmp_path / "taken.png").mkdir()                      # the target exists as a DIRECTORY: the encode runs, the write fails on the worker thread
+    script.write_text("import torch, torchvision\n"
+                      f"torchvision.utils.save_image(torch.rand(3, 8, 8), {str(tmp_path / 'taken.png')!r})\nprint('script done')\n")
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    r = subprocess.run([sys.executable, __import__("os").path.join(root, "tests", "dropin_launcher.py"), str(script)], capture_output=True, text=True, timeout=300)
+    assert "script done" in r.stdout and r.returncode != 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

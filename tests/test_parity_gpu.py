@@ -10,9 +10,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # `image` = the VAE decode of latents that already differ by `latents`: the random-init test VAE (std 0.05 weights, 4 levels) roughly
-# doubles a relative latent difference on top of its own ~2.5e-3 / 2e-2 storage rounding (tests/test_fullsize_parity_gpu.py: decode)
-TOL = {torch.float16: dict(stage=4e-3, latents=5e-3, image=1.5e-2),
-       torch.bfloat16: dict(stage=3e-2, latents=4e-2, image=1e-1)}
+# doubles a relative latent difference.  The decode itself runs the split-precision path (idm_vton_amd/vae.py) and is held to its own bar on
+# IDENTICAL latents (`decode`), so the image bar only has to cover the amplified latent drift: round 4 took it back to the round-2 values
+# (round 3 had widened it to 1.5e-2 / 1e-1 together with numeric changes -- ADVICE r3).
+TOL = {torch.float16: dict(stage=4e-3, latents=5e-3, image=1e-2, decode=2e-4),
+       torch.bfloat16: dict(stage=3e-2, latents=4e-2, image=6e-2, decode=2e-4)}
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
@@ -20,9 +22,10 @@ def test_tiny_pipeline_parity(dtype):
     from tests import parity_checks
     r = parity_checks.run("tiny", dtype, B=1, H=128, W=128, steps=4)
     t = TOL[dtype]
-    for k in ("resampler", "vae_encode", "vae_decode", "garment_feat_max", "tryon_eps", "tryon_eps_materialised_zeros",
+    for k in ("resampler", "vae_encode", "garment_feat_max", "tryon_eps", "tryon_eps_materialised_zeros",
               "prep_masked_lat", "prep_pose_lat"):
         assert r[k] <= t["stage"], (k, r)
+    assert r["vae_decode"] <= t["decode"], r                 # same latents in: the decode alone, fp32-equivalent on every engine
     assert r["closed_form_vs_materialised"] <= t["stage"], r
     assert r["latents_final"] <= t["latents"], r
     assert r["image"] <= t["image"], r
