@@ -33,12 +33,16 @@ from .unet import GarmentUNet2DConditionModel, TryonUNet2DConditionModel
 from .vae import AutoencoderKL
 
 
-def _to_tensor_image(x, name, lo_hi=None):
-    """PIL / list of PIL / ndarray / tensor -> float32 tensor [B,C,H,W] (VaeImageProcessor.preprocess semantics, B.6)."""
+def _to_tensor_image(x, name, lo_hi=None, size=None):
+    """PIL / list of PIL / ndarray / tensor -> float32 tensor [B,C,H,W] (VaeImageProcessor.preprocess semantics, B.6).
+    size = (height, width): `preprocess(image, height=, width=)` of the reference (:1588-1595) RESIZES to it -- PIL images with PIL's
+    lanczos filter (VaeImageProcessor.resize, config.resample default), tensors with F.interpolate's default (nearest)."""
     import PIL.Image
     if isinstance(x, PIL.Image.Image):
         x = [x]
     if isinstance(x, (list, tuple)) and len(x) and isinstance(x[0], PIL.Image.Image):
+        if size is not None:
+            x = [im if (im.height, im.width) == tuple(size) else im.resize((size[1], size[0]), resample=PIL.Image.LANCZOS) for im in x]
         arr = np.stack([np.asarray(im.convert("RGB") if im.mode != "L" else im, dtype=np.float32) / 255.0 for im in x])
         if arr.ndim == 3:
             arr = arr[..., None]
@@ -51,7 +55,10 @@ def _to_tensor_image(x, name, lo_hi=None):
         raise ValueError(f"`{name}` has to be a tensor, PIL image, ndarray or list of those, got {type(x)}")
     if x.ndim == 3:
         x = x.unsqueeze(0)
-    return x.float()
+    x = x.float()
+    if size is not None and tuple(x.shape[-2:]) != tuple(size):
+        x = torch.nn.functional.interpolate(x, size=tuple(size))
+    return x
 
 
 def _randn(shape, generator, device, dtype):
@@ -380,20 +387,20 @@ class StableDiffusionXLInpaintPipeline:
 
         if not cfg:                                         # :1710-1711 never read them without CFG
             negative_prompt_embeds = negative_pooled_prompt_embeds = None
-        img = _to_tensor_image(image, "image")
-        msk = _to_tensor_image(mask_image, "mask_image")
+        img = _to_tensor_image(image, "image", size=(height, width))                             # :1588-1591: resized to (height, width)
+        msk = _to_tensor_image(mask_image, "mask_image", size=(height, width))                   # :1593-1595
         if msk.shape[1] != 1:
             msk = msk.mean(dim=1, keepdim=True)                                                  # do_convert_grayscale
         pose = _to_tensor_image(pose_img, "pose_img")
         clo = _to_tensor_image(cloth, "cloth")
         B = img.shape[0]
-        if img.shape[-2:] != (height, width):
-            raise NotImplementedError(f"image size {tuple(img.shape[-2:])} != (height, width) = {(height, width)}: resize before the call")
+        for name, t in (("pose_img", pose), ("cloth", clo)):                                     # encoded as they are (:1644-1654): no resize there
+            if tuple(t.shape[-2:]) != (height, width):
+                raise ValueError(f"`{name}` is {tuple(t.shape[-2:])} but (height, width) = {(height, width)}: the reference encodes it as it "
+                                 "is and fails when its latents are concatenated with the image's")
         if img.min() < 0:
             raise ValueError("`image` is expected in [0, 1] (inference.py:408 passes (image + 1) / 2)")
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
-        if h % 4 or w % 4:
-            raise ValueError(f"latent size {h}x{w} must be a multiple of 4 (two 2x down/up-samplings without `upsample_size`)")
 
         # RNG consumption order of the reference: latents, masked-image posterior, pose posterior (GLOBAL
         # generator: tryon_pipeline.py:1646 passes none), cloth posterior, then one draw per DDPM step with t > 0

@@ -282,7 +282,9 @@ class GarmentUNet2DConditionModel(_UNetBase):
                           mid_block_additional_residual=mid_block_additional_residual,
                           down_intrablock_additional_residuals=down_intrablock_additional_residuals,
                           encoder_attention_mask=encoder_attention_mask)
-        (_, feats), _ = self._run(sample, timestep, encoder_hidden_states, None, None, None)
+        (_, feats), (_, h, w) = self._run(sample, timestep, encoder_hidden_states, None, None, None)
+        # the engine keeps round16(H*W) token rows per image; the reference's features have exactly H*W (views, no copy)
+        feats = [f if f.shape[1] == n else f[:, :n] for f, n in zip(feats, self.hip_engine().feature_tokens(h, w))]
         if not return_dict:
             return (None,), feats
         return UNet2DConditionOutput(sample=None), feats

@@ -16,6 +16,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
+    int vt_direct;                                       // measurement only (tile_hint bit 14): V^T stored straight from the accumulators
     int bias32;                                          // bias holds fp32 (plain 16-byte epilogue only): the split-precision VAE path
     float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
     float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
@@ -66,7 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const int u = lane >> 5, l31 = lane & 31;
     const T* bias = (const T*)p.bias;
     if constexpr (TR) {
-        if (fin == nullptr && p.vt_tokens % 8 == 0) {       // block-uniform
+        if (fin == nullptr && p.vt_tokens % 8 == 0 && !p.vt_direct) {       // block-uniform
             // V^T through LDS.  A lane owns ONE channel n and 4 / 8 tokens per accumulator group, so a direct store is a 16-byte piece
             // per lane, every lane in a different row of vt (stride = vt_tokens elements): 64 memory segments per instruction, and the
             // tile's 8192 pieces leave the CU at ~4 cycles each -- measured round 4: the fused QKV projection 3072x3840x1280 took 64-70 us

@@ -80,7 +80,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     }
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
     const __amdgpu_buffer_rsrc_t rs_x0 = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
-    const int hin = p.ups ? 2 * p.Hi : p.Hi, win = p.ups ? 2 * p.Wi : p.Wi;
+    // fused nearest upsample: the upsampled image IS the output grid (a same-size 3x3 / 1x1 convolution over it); Ho x Wo may be one short of
+    // 2 Hi x 2 Wi -- diffusers' `upsample_size` for skip tensors of odd size (src/unet_hacked_tryon.py:1084-1090,1357-1379): F.interpolate(size=)
+    // nearest maps output y to floor(y * Hi / Ho), which is y >> 1 for every Ho in {2 Hi - 1, 2 Hi}
+    const int hin = p.ups ? p.Ho : p.Hi, win = p.ups ? p.Wo : p.Wi;
 
     int si = 0, kseg = 0;                                // K-segment cursor of the NEXT tile to issue
     auto issue = [&](int t, int buf) {
@@ -420,6 +423,8 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     CHECK_ARG(ksum == a->Ktot, IDMVTON_E_SHAPE, "gemm_conv: segment lengths sum to %d, Ktot=%d", ksum, a->Ktot);
     CHECK_ARG(a->Ho > 0 && a->Wo > 0 && a->Hi > 0 && a->Wi > 0 && a->stride > 0 && a->M % (a->Ho * a->Wo) == 0,
               IDMVTON_E_SHAPE, "gemm_conv: geometry M=%d Ho=%d Wo=%d", a->M, a->Ho, a->Wo);
+    if (a->ups) CHECK_ARG(a->stride == 1 && a->Ho <= 2 * a->Hi && a->Ho >= 2 * a->Hi - 1 && a->Wo <= 2 * a->Wi && a->Wo >= 2 * a->Wi - 1, IDMVTON_E_SHAPE,
+                          "gemm_conv: ups=1 needs stride 1 and an output grid of 2Hi x 2Wi or one short of it (Ho=%d Hi=%d Wo=%d Wi=%d)", a->Ho, a->Hi, a->Wo, a->Wi);
     CHECK_ARG(a->w && ((uintptr_t)a->w & 15) == 0, IDMVTON_E_ALIGN, "gemm_conv: weight pointer");
     const uint64_t wbytes = (uint64_t)a->N * a->Ktot * 2;
     CHECK_ARG(wbytes + (uint64_t)128 * a->Ktot * 2 < 0xFFFFFFFFull, IDMVTON_E_SHAPE, "gemm_conv: weight too large");
@@ -461,6 +466,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     int variant = 1, bn = 64, bm = 64;
     static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
     if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
+    p.vt_direct = (a->tile_hint & 0x4000) ? 1 : 0;                              // measurement only: V^T straight from the accumulators (no LDS transpose)
     p.rowstats_out = a->rowstats_out; p.rs_parts = a->N / 32;
     p.rs_final = a->rowstats_final; p.rs_counter = a->rowstats_counter; p.rs_eps = a->rowstats_eps;
     p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec;
@@ -485,7 +491,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
         CHECK_ARG(!p.res32 || a->res, IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_RES_F32 without res");
         CHECK_ARG(p.wide, IDMVTON_E_ALIGN, "gemm_conv: the fp32 residual stream needs the 16-byte epilogue (N, ldo, ldr multiples of 8, 16-byte aligned pointers)");
     }
-    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0x7fff; }
+    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0x3fff; }
     else {
         // No hint: the largest ring tile that still gives every CU a tile (measured rule, profiles/r01_tune_report_*.json:
         // operand delivery per CU is the bound, so arithmetic intensity per tile wins until the grid no longer fills 256 CUs).

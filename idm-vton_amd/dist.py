@@ -96,6 +96,52 @@ def bcast_c_abi(flat, src=0, chunk_bytes=512 << 20):
         raise RuntimeError(L.idmvton_last_error().decode())
 
 
+class local_lock:
+    """`with local_lock("capture"):` -- one process of this HOST at a time (an flock'ed file under the temp dir, keyed by the job's
+    MASTER_PORT so two jobs on one node do not serialise each other).  Used around the first pipeline call of every rank: eight ranks
+    that capture their hipGraphs, JIT their first kernels and size their allocator pools at the same instant oversubscribe the host's
+    cores (capture is single-threaded Python + driver work per rank); staggered, each rank's start-up runs at full speed while the others
+    wait, and the timed region only begins after a barrier anyway.  No-op for a single process."""
+
+    def __init__(self, name):
+        self.name, self.f = name, None
+
+    def __enter__(self):
+        if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+            return self
+        import fcntl
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), f"idmvton_{os.environ.get('MASTER_PORT', '0')}_{self.name}.lock")
+        self.f = open(path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        if self.f is not None:
+            import fcntl
+            fcntl.flock(self.f, fcntl.LOCK_UN)
+            self.f.close()
+            self.f = None
+        return False
+
+
+def pin_host_threads(local, n_local):
+    """Give each local rank its own slice of the host cores this job may use (affinity mask split n_local ways) and size torch's intra-op
+    pool to it: eight ranks that each start a thread per core turn every host-side torch op into a fight for the same cores.
+    -> the number of cores this rank owns."""
+    if n_local <= 1 or not hasattr(os, "sched_getaffinity"):
+        return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // n_local)
+    mine = cores[(local * per) % len(cores):(local * per) % len(cores) + per] or cores[:1]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        pass
+    torch.set_num_threads(max(1, len(mine)))
+    return len(mine)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of `n_items` independent images for `rank` (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)

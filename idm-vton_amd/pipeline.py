@@ -61,12 +61,10 @@ class TryonEngine:
         H = height or image.shape[-2]
         W = width or image.shape[-1]
         h, w = H // 8, W // 8
-        # every attention level needs a multiple of 16 tokens (V^T is stored in groups of 16 keys): (H/32)*(W/32) % 16 == 0 for the
-        # three-level SDXL UNets -- say so here instead of failing inside a GEMM launch with a low-level message
-        nlev = len(self.unet.cfg.block_out_channels)
-        if H % 8 or W % 8 or (h % (1 << (nlev - 1))) or (w % (1 << (nlev - 1))) or ((h >> (nlev - 1)) * (w >> (nlev - 1))) % 16:
-            raise ValueError(f"height x width = {H} x {W} is not supported by the HIP attention kernels: the latent {h} x {w} must be divisible "
-                             f"by {1 << (nlev - 1)} and hold a multiple of 16 tokens at the coarsest level (e.g. 256x256, 512x384, 1024x768, 1536x1024)")
+        # any H x W divisible by 8 (the reference's own check, tryon_pipeline.py check_inputs): odd latent levels go through `upsample_size`
+        # (unet.py: _conv3 out_hw), token counts that are not a multiple of 16 are padded inside each Transformer2DModel (unet.py: _transformer)
+        if H % 8 or W % 8:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {H} and {W}.")
         start_is_given = bool(noise.get("latents_given"))    # the reference's `latents=` argument: used as the start as they are (:880-882)
         if strength < 1.0 and noise.get("image") is None and not start_is_given:
             raise ValueError("strength < 1 starts from add_noise(encode(image)): pass the posterior draw of the init-image encode as "

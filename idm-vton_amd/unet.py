@@ -213,8 +213,10 @@ class HipUNet:
         return ops.groupnorm(xa, sd[name + ".weight"], sd[name + ".bias"], self.cfg.norm_num_groups, eps, silu,
                              self._gn_stats, x2=xb)
 
-    def _conv3(self, x, cv, B, H, W, stride=1, ups=False, extra_segs=(), **kw):
-        Ho, Wo = (H * 2, W * 2) if ups else ((H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1)
+    def _conv3(self, x, cv, B, H, W, stride=1, ups=False, extra_segs=(), out_hw=None, **kw):
+        """out_hw (ups only): the skip tensor's H x W when it is odd -- diffusers' `upsample_size` (unet_hacked_tryon.py:1357-1379): the fused
+        nearest upsample then produces 2H - 1 rows / 2W - 1 columns instead of 2H / 2W."""
+        Ho, Wo = (out_hw or (H * 2, W * 2)) if ups else ((H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1)
         segs = ops.conv_segs(x, 3, 1, length=cv.cin_pad) + list(extra_segs)
         out = ops.gemm_conv(segs, cv.w, B * Ho * Wo, Ho=Ho, Wo=Wo, Hi=H, Wi=W, stride=stride, ups=ups, bias=cv.b, **kw)
         return out.view(B, Ho * Wo, cv.n), Ho, Wo
@@ -235,11 +237,14 @@ class HipUNet:
             out, _, _ = self._conv3(g2, r["conv2"], B, H, W, res=xa.reshape(B * H * W, -1))
         return out
 
-    def _block(self, blk, hs, B, N, C, ctx, garment, feats_out, stop=None, last=False):
-        """BasicTransformerBlock: tryon src/attentionhacked_tryon.py:284-415, garmnet src/attentionhacked_garmnet.py:284-406."""
+    def _block(self, blk, hs, B, N, C, ctx, garment, feats_out, stop=None, last=False, nk=None):
+        """BasicTransformerBlock: tryon src/attentionhacked_tryon.py:284-415, garmnet src/attentionhacked_garmnet.py:284-406.
+        N = token ROWS per image (a multiple of 16: the V^T layout works in groups of 16 keys); nk = the real token count when the rows
+        are padded (sizes whose H*W is not a multiple of 16: rows nk..N-1 hold finite filler that no key / output ever reads)."""
         sd, p, heads = self.sd, blk["p"], blk["heads"]
         dt, dev = self.dtype, self.device
         M = B * N
+        nk = N if nk is None else nk
         feat = None
         fuse = self.fuse_ln
         rs = self._rowstats_buf(M, C) if fuse else None          # row statistics of the current hidden state (written by its producer)
@@ -258,19 +263,23 @@ class HipUNet:
                 if stop is not None and len(feats_out) >= stop:
                     return None                          # GarmentNet: everything after the last export is dead compute
             ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE)
-        segs = [dict(k=qk[:, C:], vt=vt, nk=N, ldk=2 * C, ldvt=N)]
+        segs = [dict(k=qk[:, C:], vt=vt, nk=nk, ldk=2 * C, ldvt=N, k_rows=N)]
         if self.tryon:
             if garment.get("kv") is not None:                   # K / V^T of the garment tokens projected ahead of time
                 kg, vtg = garment["kv"][garment["idx"]]         # (project_garment_kv, on the GarmentNet stream)
                 Bg = vtg.shape[0]
             else:
-                g = garment["feats"][garment["idx"]]            # [Bg][N][C]
+                g = garment["feats"][garment["idx"]]            # [Bg][N][C] (or [Bg][nk][C]: reference-shaped features of a padded size)
                 Bg = g.shape[0]
+                if g.shape[1] != N:
+                    gp = torch.zeros(Bg, N, C, dtype=dt, device=dev)
+                    gp[:, :g.shape[1]] = g
+                    g = gp
                 kg = torch.empty(Bg * N, C, dtype=dt, device=dev)
                 vtg = torch.empty(Bg, C, N, dtype=dt, device=dev)
                 ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
             garment["idx"] += 1
-            segs.append(dict(k=kg, vt=vtg, nk=N, ldk=C, ldvt=N, b0=B - Bg))
+            segs.append(dict(k=kg, vt=vtg, nk=nk, ldk=C, ldvt=N, k_rows=N, b0=B - Bg))
         att = torch.empty(M, C, dtype=dt, device=dev)
         if self.attn_fp8:
             eq, ek, ev = self.f8_exp
@@ -279,7 +288,7 @@ class HipUNet:
                 Bs = sg["vt"].shape[0]
                 k8 = ops.quant_f8(sg["k"], 2.0 ** ek)                                   # [Bs*N][C] (row stride ldk)
                 vt8 = ops.quant_f8(sg["vt"].reshape(Bs * C, N), 2.0 ** ev, mode=1)      # 16-bit key order -> fp8 slot order
-                segs8.append(dict(k8=k8, vt8=vt8, nk=N, ldk=C, ldvt=vt8.shape[1], b0=sg.get("b0", 0)))
+                segs8.append(dict(k8=k8, vt8=vt8, nk=nk, ldk=C, ldvt=vt8.shape[1], k_rows=N, b0=sg.get("b0", 0)))
             q8 = ops.quant_f8(qk[:, :C], 2.0 ** eq)
             ops.attention_f8(q8, att, segs8, heads, qk_scale_exp=-(eq + ek), v_scale_exp=-ev, B=B, Nq=N, ldq=C, ldo=C)
         else:
@@ -324,15 +333,34 @@ class HipUNet:
         """Transformer2DModel (src/transformerhacked_tryon.py:246-467), NHWC so no permutes."""
         sd, tf = self.sd, self.tf[p]
         C, N = tf["ch"], H * W
+        Np = ops.round16(N)                                  # token rows per image inside the transformer (V^T works in groups of 16 keys)
         g = self._gn(x, None, p + ".norm", 1e-6, False)
-        hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32,
-                        rowstats_out=self._rowstats_buf(B * N, C) if (self.fuse_ln and self.tryon) else None)
+        rs = self._rowstats_buf(B * Np, C) if (self.fuse_ln and self.tryon) else None
+        if Np == N:
+            hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32, rowstats_out=rs)
+        else:
+            # H*W not a multiple of 16 (e.g. 320x320 -> 10x10 tokens at the coarsest level): proj_in as a 1x1 convolution from an N-pixel row
+            # to an Np-pixel row per image -- rows N..Np-1 read outside the image (zeros -> bias): finite filler the attention masks as keys
+            hs = ops.gemm_conv([ops.SegSpec(g, 0, C)], sd[p + ".proj_in.weight"], B * Np, Ho=1, Wo=Np, Hi=1, Wi=N, bias=sd[p + ".proj_in.bias"],
+                               out_f32=self.stream_f32, rowstats_out=rs)
         for blk in tf["blocks"]:
-            hs = self._block(blk, hs, B, N, C, ctx, garment, feats_out, stop_after_feats, last=blk is tf["blocks"][-1])
+            hs = self._block(blk, hs, B, Np, C, ctx, garment, feats_out, stop_after_feats, last=blk is tf["blocks"][-1], nk=N)
             if hs is None:
                 return None
-        out = ops.linear(hs, sd[p + ".proj_out.weight"], bias=sd[p + ".proj_out.bias"], res=x.reshape(B * N, C))
+        if Np == N:
+            out = ops.linear(hs, sd[p + ".proj_out.weight"], bias=sd[p + ".proj_out.bias"], res=x.reshape(B * N, C))
+        else:
+            out = ops.gemm_conv([ops.SegSpec(hs.view(B, Np, C), 0, C)], sd[p + ".proj_out.weight"], B * N, Ho=1, Wo=N, Hi=1, Wi=Np,
+                                bias=sd[p + ".proj_out.bias"], res=x.reshape(B * N, C))
         return out.view(B, N, C)
+
+    def feature_tokens(self, h, w):
+        """Real token count of each exported / consumed garment feature at latent size h x w (features are returned with round16 rows)."""
+        lv = [(h, w)]
+        for _ in range(len(self.cfg.block_out_channels) - 1):
+            lv.append(((lv[-1][0] + 1) // 2, (lv[-1][1] + 1) // 2))
+        ch2lv = {c: i for i, c in enumerate(self.cfg.block_out_channels)}
+        return [lv[ch2lv[tf["ch"]]][0] * lv[ch2lv[tf["ch"]]][1] for tf in self.tf.values() for _ in tf["blocks"]]
 
     def num_features(self):
         return sum(len(t["blocks"]) for t in self.tf.values())
@@ -382,14 +410,16 @@ class HipUNet:
                 continue
             for j in range(len(blk["resnets"])):
                 s, sh, sw = skips.pop()
-                assert (sh, sw) == (H, W), "skip/upsample size mismatch (H, W must be multiples of 2^num_upsamplers)"
+                assert (sh, sw) == (H, W), "skip / upsample size mismatch"
                 h = self._resnet(f"up_blocks.{i}.resnets.{j}", h, s, temb, B, H, W)
                 if blk["attn"]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, B, H, W, ctx, garment, feats, stop)
                     if h is None:
                         return None, feats
             if blk["up"]:
-                h, H, W = self._conv3(h, self.res[f"up_blocks.{i}.upsamplers.0.conv"], B, H, W, ups=True)
+                # `upsample_size` (unet_hacked_tryon.py:1084-1090,1357-1379): the next skip's H x W, which is 2H - 1 / 2W - 1 for an odd level
+                tgt = (skips[-1][1], skips[-1][2]) if skips else (2 * H, 2 * W)
+                h, H, W = self._conv3(h, self.res[f"up_blocks.{i}.upsamplers.0.conv"], B, H, W, ups=True, out_hw=tgt)
         if not self.tryon:
             return None, feats
         g = self._gn(h, None, "conv_norm_out", self.cfg.norm_eps, True)

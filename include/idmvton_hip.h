@@ -40,7 +40,8 @@ int idmvton_sizeof(const char* struct_name); /* sizeof() of an args struct by na
  *
  * X is a virtual [M][Ktot] matrix assembled from `nseg` K-segments.  Segment s contributes `len` (multiple of 64)
  * consecutive k; row m = (b, oy, ox) of the OUTPUT grid reads input pixel
- *     (iy, ix) = (oy*stride + dy, ox*stride + dx)        [>>1 each when ups=1: fused nearest-2x upsample]
+ *     (iy, ix) = (oy*stride + dy, ox*stride + dx)        [>>1 each when ups=1: fused nearest upsample to the Ho x Wo grid, which is
+ *                                                          2Hi x 2Wi or one short of it (diffusers `upsample_size`, odd skip sizes); stride 1]
  * of the NHWC tensor `ptr` ([B][Hi][Wi][pitch]) at channels [coff, coff+len); out-of-image taps read 0.
  * A Linear is one segment with Ho=Hi=1, Wo=Wi=M.  A 3x3 conv is 9 segments; channel-concatenated inputs
  * (torch.cat at unet_block_hacked_tryon.py:2346,2482) are extra segments on a second pointer; the 1x1 conv_shortcut

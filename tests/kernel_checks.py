@@ -110,6 +110,19 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+def check_conv_ups_odd(B, Cin, Cout, H, W, Ho, Wo, dtype, dev, seed=0):
+    """Upsample2D with `upsample_size` (F.interpolate(size=(Ho, Wo)) nearest, Ho in {2H - 1, 2H}) + 3x3 conv, fused in the gather."""
+    from idm_vton_amd import ops
+    from idm_vton_amd.weights import conv_weight_nhwc
+    x = _r(B, H, W, Cin, dtype=dtype, dev=dev, seed=seed)
+    w = _r(Cout, Cin, 3, 3, dtype=dtype, dev=dev, scale=(9 * Cin) ** -0.5, seed=seed + 1)
+    b = _r(Cout, dtype=dtype, dev=dev, seed=seed + 2)
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), size=(Ho, Wo), mode="nearest")
+    ref = F.conv2d(up, w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
+    out = ops.gemm_conv(ops.conv_segs(x, 3, 1), conv_weight_nhwc(w), B * Ho * Wo, Ho=Ho, Wo=Wo, Hi=H, Wi=W, ups=True, bias=b)
+    return relerr(out, ref)
+
+
 def check_conv(B, Cin, Cout, H, W, dtype, dev, k=3, stride=1, ups=False, split=0, shortcut=0, temb=False, res=False,
                seed=0, tile_hint=0):
     """3x3 / 1x1 conv over NHWC with the fused extras of ResnetBlock2D:
@@ -846,6 +859,8 @@ def all_checks(dev="cuda"):
         add("groupnorm_reproducible_320", lambda dt=dt: check_groupnorm_reproducible(4, 12288, 320, dt, dev), 0.0)
         add("groupnorm_reproducible_2560", lambda dt=dt: check_groupnorm_reproducible(2, 768, 2560, dt, dev), 0.0)
         add("elementwise", lambda dt=dt: check_elementwise(2, 16, 12, dt, dev))
+        add("conv3x3_ups_to_odd_grid_63x47", lambda dt=dt: check_conv_ups_odd(2, 128, 128, 32, 24, 63, 47, dt, dev))
+        add("conv3x3_ups_to_mixed_grid_17x26", lambda dt=dt: check_conv_ups_odd(1, 64, 192, 9, 13, 17, 26, dt, dev))
     # the split-precision (fp32-equivalent) path of the VAE decode: operand pairs are bf16 whatever the engine's storage type.  Bars: a
     # 3-term product carries ~2^-16 per operand (measured ~3e-6 of the output range); the 16-bit path sits at 2e-3 (fp16) / 1.6e-2 (bf16)
     from idm_vton_amd import ffi

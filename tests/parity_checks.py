@@ -42,6 +42,7 @@ def run(kind="tiny", dtype=torch.float16, B=1, H=128, W=128, steps=4, scheduler=
     x_g = ops.to_nhwc(z_o.to(device).float().contiguous(), dtype, cpad=p_g.cin_pad)
     _, f_p = p_g.forward(x_g, temb_g, ctx_g, B, h, w)
     assert len(f_o) == len(f_p) == p_g.num_features()
+    f_p = [f[:, :n] for f, n in zip(f_p, p_g.feature_tokens(h, w))]        # the engine keeps round16(H*W) token rows per image
     errs = [pu.relerr(a, b) for a, b in zip(f_p, f_o)]
     res["garment_feat_first"], res["garment_feat_last"], res["garment_feat_max"] = errs[0], errs[-1], max(errs)
 

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(ffi.SYMBOLS), declared ^ set(ffi.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.idmvton_abi_version() == 5
+    assert L.idmvton_abi_version() == ffi.ABI_VERSION == 6
 
 
 def test_arg_validation_without_gpu():
@@ -227,3 +227,37 @@ def test_bench_shutdown_has_a_deadline():
     while threading.active_count() > n0 and time.time() - t0 < 5.0:      # a cancelled Timer thread ends on its own, promptly
         time.sleep(0.05)
     assert threading.active_count() <= n0
+
+
+def test_bench_rank_logic_at_world_8_under_gloo(tmp_path):
+    """no 8-GPU node is available to this build, so everything of `bench.py --gpus 8` that is not the engine runs here at
+    the REAL rank count with a stand-in engine (`--stub-engine`, CPU, gloo): the self-launcher with a free rendezvous port, init from the
+    launcher's env, the world-size check, per-rank core pinning, the flock-staggered warm-up (no two ranks of the host warm up at once),
+    barriers, max over ranks, ONE JSON line from rank 0, teardown of all 8 ranks within the deadline."""
+    import json
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["IDMVTON_STUB_TRACE"] = str(tmp_path / "trace")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--stub-engine"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["rccl_ranks"] == 8
+    # the slowest rank sleeps 30 ms per call: the job's time is the max over ranks, the value counts all 8 ranks' images
+    assert 0.03 * 3 * 0.9 <= d["ms_per_step"] * 3 / 1e3 <= 5.0
+    assert abs(d["value"] - 8 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
+    # warm-up calls (the first call of every rank) never overlapped: the staggering lock works across 8 processes
+    first = []
+    for rk in range(8):
+        rows = [tuple(map(float, ln.split())) for ln in open(f"{env['IDMVTON_STUB_TRACE']}.{rk}")]
+        assert len(rows) == 4                                                  # 1 warm-up + 3 timed calls
+        first.append(rows[0])
+    first.sort()
+    for (a0, a1), (b0, b1) in zip(first, first[1:]):
+        assert b0 >= a1 - 2e-3, (a0, a1, b0, b1)
+    assert time.time() - t0 < 300
