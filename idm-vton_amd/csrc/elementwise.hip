@@ -270,7 +270,7 @@ extern "C" int idmvton_sizeof(const char* name) {
 #define SZ(n) if (!strcmp(name, #n)) return (int)sizeof(n);
     SZ(idmvton_seg) SZ(idmvton_gemm_conv_args) SZ(idmvton_attn_args) SZ(idmvton_layernorm_args)
     SZ(idmvton_groupnorm_args) SZ(idmvton_pack_input_args) SZ(idmvton_cfg_step_args) SZ(idmvton_layout_args)
-    SZ(idmvton_vae_sample_args) SZ(idmvton_softmax_args) SZ(idmvton_attn_small_args) SZ(idmvton_attn_f8_args) SZ(idmvton_quant_f8_args) SZ(idmvton_split_args)
+    SZ(idmvton_vae_sample_args) SZ(idmvton_softmax_args) SZ(idmvton_attn_small_args) SZ(idmvton_attn_f8_args) SZ(idmvton_quant_f8_args) SZ(idmvton_split_args) SZ(idmvton_xattn)
 #undef SZ
     return -1;
 }

@@ -2,6 +2,7 @@
 // hand-scheduled Linear main loop): kernel parameter block and the accumulator epilogue.
 #pragma once
 #include "common.cuh"
+#include "xattn.cuh"
 
 struct GemmParams {
     const void* w; uint32_t w_bytes; int N; int Ktot;
@@ -16,11 +17,11 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
-    int vt_direct;                                       // measurement only (tile_hint bit 14): V^T stored straight from the accumulators
     int bias32;                                          // bias holds fp32 (plain 16-byte epilogue only): the split-precision VAE path
     float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
     float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
     const float* ln_rowstats; const float* ln_colvec;    // consumer: LayerNorm folded into this GEMM (ln_rowstats = a producer's rs_final)
+    XAttnParams xa;                                      // mode IDMVTON_EPI_XATTN: cross-attention applied to the accumulators (xattn.cuh)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -39,10 +40,9 @@ __device__ __forceinline__ void swap_cols8(const f32x16& c, const int gp, float 
 }
 
 // Epilogue shared by every main loop: acc[ni][mi] is the wave's (SN x SM) sub-tile as NI x MI 32x32 accumulators (TR: D[m][n]).
-// BN x BM = the workgroup's tile, NT its thread count, smem its LDS (>= BN * BM * 2 bytes, free once the main loop is done).
-template <typename T, int NI, int MI, int SN, int SM, bool TR, int BN, int BM, int NT>
+template <typename T, int NI, int MI, int SN, int SM, bool TR>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[NI][MI], const int m0, const int n0, const int wn, const int wm,
-                                              const int lane, const float* fin, char* smem) {
+                                              const int lane, const float* fin) {
     // Folded LayerNorm (fin != nullptr, block-uniform): every accumulator value a of row m, column n becomes
     //     rstd[m] * a - rstd[m]*mean[m] * s[n] + c[n]        ((rstd, -rstd*mean) = fin[2*row_in_tile ..], s = ln_colvec, c = ln_colvec + N)
     // right where it is consumed (8 / 4 values at a time, like the bias): a separate pass over the accumulators costs 30-90 extra
@@ -67,63 +67,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const int u = lane >> 5, l31 = lane & 31;
     const T* bias = (const T*)p.bias;
     if constexpr (TR) {
-        if (fin == nullptr && p.vt_tokens % 8 == 0 && !p.vt_direct) {       // block-uniform
-            // V^T through LDS.  A lane owns ONE channel n and 4 / 8 tokens per accumulator group, so a direct store is a 16-byte piece
-            // per lane, every lane in a different row of vt (stride = vt_tokens elements): 64 memory segments per instruction, and the
-            // tile's 8192 pieces leave the CU at ~4 cycles each -- measured round 4: the fused QKV projection 3072x3840x1280 took 64-70 us
-            // against 42 us for the same GEMM without a transposed part (profiles/r04_gemm_probe_*.log).  Transposed in LDS instead:
-            // [n][BM tokens] rows (16-byte chunk c of row n at chunk c ^ (n & (chunks - 1)): conflict-free both ways), then each wave
-            // writes whole 128-byte lines of vt, 16 bytes per lane.
-            T* vt = (T*)p.vt;
-            const int Cv = p.N - p.vt_n0;
-            constexpr int ROWB = BM * 2, NCH = BM / 8;
-            static_assert((NCH & (NCH - 1)) == 0 && NT % NCH == 0, "row chunks");
-            __syncthreads();                                 // every wave is done with the last k-tile's LDS image
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int nl = wn * SN + ni * 32 + l31;
-                const float bv = (bias && n0 + nl < p.N) ? (float)bias[n0 + nl] : 0.f;
-                char* row = smem + nl * ROWB;
-                const int key = nl & (NCH - 1);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    if (p.vt_perm) {                         // registers 8gp + j = key-order positions 16gp + 8u + j of the 32-row group
-#pragma unroll
-                        for (int gp = 0; gp < 2; ++gp) {
-                            v8 o;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (T)(acc[ni][mi][8 * gp + j] + bv);
-                            const int ch = (wm * SM + mi * 32 + 16 * gp + 8 * u) >> 3;
-                            *(v8*)(row + ((ch ^ key) << 4)) = o;
-                        }
-                    } else {                                 // registers 4g + j = rows 8g + 4u + j (plain transpose)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            v4 o;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
-                            const int pos = wm * SM + mi * 32 + 8 * g + 4 * u;
-                            *(v4*)(row + (((pos >> 3) ^ key) << 4) + (pos & 4) * 2) = o;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            const int tid = threadIdx.x;
-            const int j = tid % NCH;                         // this thread's chunk of every row it stores: tokens m0 + 8j .. + 7
-            const int m = m0 + 8 * j;
-            if (m < p.M) {                                   // M % 8 == 0 (vt_tokens % 8 == 0): a chunk is inside or outside as a whole
-                const int b = m / p.vt_tokens;
-                const int tok = m - b * p.vt_tokens;
-                T* dst = vt + ((size_t)b * Cv + (n0 - p.vt_n0)) * p.vt_tokens + tok;
-#pragma unroll 4
-                for (int r = tid / NCH; r < BN; r += NT / NCH) {
-                    if (n0 + r >= p.N) break;
-                    *(v8*)(dst + (size_t)r * p.vt_tokens) = *(const v8*)(smem + r * ROWB + ((j ^ (r & (NCH - 1))) << 4));
-                }
-            }
-            return;
-        }
         if (p.vt_perm) {
             // key order puts the tokens of accumulator groups g = 2gp, 2gp+1 (rows 8g + 4u + j) next to each other: 16 gp + 8u + 4(g&1) + j
             T* vt = (T*)p.vt;

@@ -22,6 +22,7 @@
 // LIN = plain Linear (one K segment, no spatial gather): the activation operand's DMA offsets are precomputed like the
 // weight's, so issuing a tile costs one add per DMA instead of the ~12 VALU of the conv gather.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #if !defined(__gfx950__) && !defined(__gfx942__) && defined(__HIP_DEVICE_COMPILE__)
 #error "gemm_conv.hip: the in-launch LayerNorm hand-off and the counted vmcnt pipeline are written for gfx94x/gfx950 (stores counted in vmcnt)"
@@ -32,7 +33,7 @@
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR>
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR, bool XA = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
@@ -218,6 +219,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     float2 ln_ab = make_float2(1.f, 0.f);
     if (p.ln_rowstats && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) ln_ab = ((const float2*)p.ln_rowstats)[m0 + threadIdx.x];
 
+    // fused cross-attention (xattn.cuh): this wave's head and batch element; its K fragments travel under the main loop
+    v8 xkf[XA ? XA_NK : 1];
+    int xa_b = 0, xa_h = 0;
+    if constexpr (XA) {
+        static_assert(NI == 2 && !TR, "fused cross-attention: one 64-channel head per wave");
+        const int mw = m0 + wm * SM;
+        xa_b = (mw < p.M ? mw : p.M - 1) / p.xa.tokens;
+        xa_h = (n0 + wn * SN) >> 6;
+        xattn_load_k<T>(p.xa, xa_b, xa_h, lane, xkf);
+    }
     const int nt = p.Ktot >> 6;
     if constexpr (!V1) {
         issue(0, 0);
@@ -252,7 +263,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         __syncthreads();
         fin = (const float*)smem;
     }
-    gemm_epilogue<T, NI, MI, SN, SM, TR, BN, BM, NW * 64>(p, acc, m0, n0, wn, wm, lane, fin, smem);
+    if constexpr (XA) {                                  // the accumulators are q of one head per wave: replace them by the cross-attention output
+        v8 xvf[XA_NV];
+        xattn_load_v<T>(p.xa, xa_b, xa_h, lane, xvf);
+        xattn_compute<T, MI>(p.xa, p.M, acc, m0 + wm * SM, lane, xkf, xvf);
+    }
+    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, fin);
 
     if (p.rs_counter) {                                  // block-uniform: producer of LayerNorm row statistics
         // Inter-workgroup hand-off inside the launch (guide G16, "payload write-through + counter"): the partials left as agent-scope
@@ -354,6 +370,20 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
     }
 }
 
+// The query projection of a cross-attention with the attention itself as its epilogue (xattn.cuh): plain Linear loader, ring pipeline.
+template <typename T, int BN, int BM, int WN, int WM, int ST, int OCC>
+__global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_xattn_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
+    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    constexpr int GM = 1024 / BM;
+    const int width = GM * p.tiles_n;
+    const int grp = wg / width, rem = wg - grp * width;
+    const int first = grp * GM;
+    const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
+    const int tn = rem / gsz, tm = first + (rem - tn * gsz);
+    gemm_body<T, BN, BM, WN, WM, ST, true, true, OCC == 1, false, true>(p, smem, tm * BM, tn * BN);
+}
+
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
 static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
@@ -363,8 +393,8 @@ static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, V1, false, OCC, PFX>), grid, block, 0, st, p);
 }
 
-// gemm_lin.hip: the hand-scheduled 256x256 Linear main loop (variant 5: 8 waves x 128x64)
-int launch_gemm_lin(const GemmParams& p, bool bf16, int form, hipStream_t st);
+// gemm_lin.hip: the hand-scheduled Linear main loop (variant 5: 256x256 as 8 waves x 128x64, 256x192 as 8 waves x 64x96)
+int launch_gemm_lin(const GemmParams& p, bool bf16, int bm, int form, hipStream_t st);
 
 template <typename T>
 static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool lin, hipStream_t st) {
@@ -373,6 +403,19 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
     if (variant == 5) { form = bm & 15; bm &= ~15; }       // placement form under measurement: low nibble of the BM field
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tiles_m = (p.M + bm - 1) / bm;
+    if (p.mode == IDMVTON_EPI_XATTN) {                   // tiles whose waves own 64 columns: 128x64, 128x128 (2x2 waves), 128x256 (2x4)
+        if (bm != 64 && p.xa.tokens % 64 != 0) {         // a wave's rows must lie in one batch element: 64-row waves need tokens % 64 == 0
+            bm = 64;
+            p.tiles_m = (p.M + bm - 1) / bm;
+        }
+        const dim3 grid(p.tiles_n * p.tiles_m);
+        if (bn == 128 && bm == 64) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 64, 2, 2, 3, 2>), grid, dim3(256), 0, st, p);
+        else if (bn == 128 && bm == 128) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 128, 2, 2, 3, 1>), grid, dim3(256), 0, st, p);
+        else if (bn == 128 && bm == 256) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 256, 2, 4, 3, 2>), grid, dim3(512), 0, st, p);
+        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN runs on the 128x64, 128x128 and 128x256 tiles (got %dx%d)", bn, bm);
+        CHECK_LAUNCH("gemm_conv");
+        return IDMVTON_OK;
+    }
     if (variant == 0) {
         if (bn == 128 && bm == 128) launch_cfg<T, 128, 128, 2, 2, 2, false, 2>(p, lin, st);
         else if (bn == 128 && bm == 64) launch_cfg<T, 128, 64, 2, 2, 2, false, 3>(p, lin, st);
@@ -396,9 +439,10 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         if (p.wide && !p.vt) launch_cfg<T, 256, 256, 2, 2, 2, true, 1>(p, lin, st);
         else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue or a V^T part: the 8-wave tile
     } else if (variant == 5) {                           // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
-        if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 5 is the 256x256 tile");
-        if (lin && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, std::is_same<T, bf16_t>::value, form, st);
-        else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);
+        if (!(bn == 256 && (bm == 256 || bm == 192))) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 5 is the 256x256 / 256x192 tile");
+        if (lin && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, std::is_same<T, bf16_t>::value, bm, form, st);
+        else if (bm == 256) launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);
+        else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: the 256x192 tile is a plain-Linear tile (one K segment, no gather, no folded LayerNorm)");
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;
@@ -428,8 +472,8 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     CHECK_ARG(a->w && ((uintptr_t)a->w & 15) == 0, IDMVTON_E_ALIGN, "gemm_conv: weight pointer");
     const uint64_t wbytes = (uint64_t)a->N * a->Ktot * 2;
     CHECK_ARG(wbytes + (uint64_t)128 * a->Ktot * 2 < 0xFFFFFFFFull, IDMVTON_E_SHAPE, "gemm_conv: weight too large");
-    const bool geglu = a->mode == IDMVTON_EPI_GEGLU;
-    CHECK_ARG(a->mode == IDMVTON_EPI_NONE || a->mode == IDMVTON_EPI_GELU || a->mode == IDMVTON_EPI_QUICKGELU || geglu, IDMVTON_E_ARG, "gemm_conv: mode %d", a->mode);
+    const bool geglu = a->mode == IDMVTON_EPI_GEGLU, xattn = a->mode == IDMVTON_EPI_XATTN;
+    CHECK_ARG(a->mode == IDMVTON_EPI_NONE || a->mode == IDMVTON_EPI_GELU || a->mode == IDMVTON_EPI_QUICKGELU || geglu || xattn, IDMVTON_E_ARG, "gemm_conv: mode %d", a->mode);
     CHECK_ARG(a->colscale_n >= 0 && a->colscale_n % 4 == 0 && !(geglu && a->colscale_n), IDMVTON_E_ARG, "gemm_conv: colscale_n=%d", a->colscale_n);
     if (geglu) CHECK_ARG(a->N % 64 == 0 && !a->res && !a->rowbias && !a->vt, IDMVTON_E_ARG, "gemm_conv: GEGLU needs N%%64==0, no res/rowbias/vt");
     CHECK_ARG(a->out || (a->vt && a->vt_n0 == 0), IDMVTON_E_ARG, "gemm_conv: null out");
@@ -445,6 +489,22 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
                          IDMVTON_E_ARG, "gemm_conv: vt_tokens=%d vt_n0=%d", a->vt_tokens, a->vt_n0);
 
     GemmParams p;
+    memset(&p.xa, 0, sizeof(p.xa));
+    if (xattn) {
+        const idmvton_xattn* x = a->xattn;
+        CHECK_ARG(x != nullptr && (x->nseg == 1 || x->nseg == 2), IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN needs `xattn` with 1 or 2 key segments");
+        CHECK_ARG(a->N % 64 == 0 && !a->bias && !a->res && !a->rowbias && !a->vt && !a->colscale_n && !a->io_flags && !a->ln_rowstats && !a->rowstats_out &&
+                  a->nseg == 1 && a->Ho == 1 && a->Hi == 1 && a->Wo == a->M && a->Wi == a->M && a->out && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0,
+                  IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN is a plain Linear with N %% 64 == 0 and nothing else in its epilogue");
+        CHECK_ARG(x->tokens > 0 && x->tokens % 32 == 0 && a->M % x->tokens == 0, IDMVTON_E_SHAPE, "gemm_conv: xattn.tokens=%d (rows per batch element, a multiple of 32 dividing M=%d)", x->tokens, a->M);
+        for (int s = 0; s < x->nseg; ++s) {
+            CHECK_ARG(x->k[s] && x->vt[s] && x->nk[s] > 0 && x->nk[s] <= 96 && x->k_rows[s] >= ((x->nk[s] + 31) & ~31) && x->ldk[s] >= a->N && x->ldk[s] % 8 == 0 &&
+                      x->ldvt[s] >= ((x->nk[s] + 15) & ~15) && x->ldvt[s] % 8 == 0 && (((uintptr_t)x->k[s] | (uintptr_t)x->vt[s]) & 15) == 0, IDMVTON_E_SHAPE,
+                      "gemm_conv: xattn segment %d: nk=%d (<= 96) k_rows=%d (>= round32(nk)) ldk=%d ldvt=%d (>= round16(nk))", s, x->nk[s], x->k_rows[s], x->ldk[s], x->ldvt[s]);
+            p.xa.k[s] = x->k[s]; p.xa.vt[s] = x->vt[s]; p.xa.ldk[s] = x->ldk[s]; p.xa.ldvt[s] = x->ldvt[s]; p.xa.nk[s] = x->nk[s]; p.xa.krows[s] = x->k_rows[s];
+        }
+        p.xa.nseg = x->nseg; p.xa.tokens = x->tokens; p.xa.vchan = a->N; p.xa.ip_scale = x->ip_scale;
+    } else CHECK_ARG(a->xattn == nullptr, IDMVTON_E_ARG, "gemm_conv: `xattn` without mode IDMVTON_EPI_XATTN");
     p.w = a->w; p.w_bytes = (uint32_t)wbytes; p.N = a->N; p.Ktot = a->Ktot;
     p.nseg = a->nseg;
     for (int s = 0; s < IDMVTON_MAX_SEG; ++s) p.seg[s] = a->seg[s < a->nseg ? s : a->nseg - 1];
@@ -466,7 +526,6 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     int variant = 1, bn = 64, bm = 64;
     static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
     if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
-    p.vt_direct = (a->tile_hint & 0x4000) ? 1 : 0;                              // measurement only: V^T straight from the accumulators (no LDS transpose)
     p.rowstats_out = a->rowstats_out; p.rs_parts = a->N / 32;
     p.rs_final = a->rowstats_final; p.rs_counter = a->rowstats_counter; p.rs_eps = a->rowstats_eps;
     p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec;
@@ -491,7 +550,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
         CHECK_ARG(!p.res32 || a->res, IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_RES_F32 without res");
         CHECK_ARG(p.wide, IDMVTON_E_ALIGN, "gemm_conv: the fp32 residual stream needs the 16-byte epilogue (N, ldo, ldr multiples of 8, 16-byte aligned pointers)");
     }
-    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0x3fff; }
+    if (a->tile_hint) { variant = (a->tile_hint >> 28) & 0xf; bn = (a->tile_hint >> 16) & 0xfff; bm = a->tile_hint & 0x7fff; }
     else {
         // No hint: the largest ring tile that still gives every CU a tile (measured rule, profiles/r01_tune_report_*.json:
         // operand delivery per CU is the bound, so arithmetic intensity per tile wins until the grid no longer fills 256 CUs).
@@ -499,6 +558,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
         for (int i = 0; i < 5; ++i) {
             const int n_ = cand[i][0], m_ = cand[i][1];
             if (geglu && n_ < 128) continue;
+            if (xattn && (n_ != 128)) continue;          // waves must own 64 columns (one head): the 128-column tiles
             if (a->vt && a->vt_n0 % n_ != 0) continue;
             // a tile wider than the (64-rounded) problem wastes its surplus columns' MFMAs: N = 128 on the 256-column tile ran the
             // VAE's full-resolution 128-channel convolutions at half rate (profiles/r03_v2_prof_default_kernel_stats_by_grid.txt)
@@ -512,6 +572,9 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     const idmvton_seg& s0 = a->seg[0];
     const bool lin = a->nseg == 1 && a->Ho == 1 && a->Hi == 1 && a->Wo == a->M && a->Wi == a->M && a->stride == 1 &&
                      !a->ups && s0.dy == 0 && s0.dx == 0 && (uint64_t)a->M * s0.pitch * 2 < 0x80000000ull;
+    // no hint and the heuristic chose the 256x256 tile for a plain Linear: the hand-scheduled loop (gemm_lin.hip) won on every such shape it
+    // was measured on (profiles/r04_gemm_probe_*.log: +5..11 % over the compiler-scheduled tile)
+    if (!a->tile_hint && bn == 256 && bm == 256 && lin && !a->ln_rowstats && !a->rowstats_counter) { variant = 5; bm = 257; }
     hipStream_t st = (hipStream_t)stream;
     return a->dtype == IDMVTON_BF16 ? launch_gemm<bf16_t>(p, variant, bn, bm, lin, st) : launch_gemm<f16_t>(p, variant, bn, bm, lin, st);
 }

@@ -2,88 +2,114 @@
 // statistics in fp32, optional second output = GarmentNet feature export) and NHWC GroupNorm(+SiLU) as
 // stats (per-channel fp32 partials -> per-(block,batch,group) double partials, deterministic) + finalize + apply (16-byte vector loads/stores, the
 // per-thread channel chunk's scale/shift held in registers).  See include/idmvton_hip.h for the reference call sites.
+#include <cstdlib>
 #include "common.cuh"
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave per row; lane l owns 8-element chunks l, l+64, l+128, l+192 (C <= 2048).  16-byte loads, fp32 math.
-template <typename T, int NCH, bool X32>
+// One wave per RPW rows (RPW = 1 is what runs, see launch_ln); lane l owns 8-element chunks l, l+64, l+128, l+192 (C <= 2048) of each.
+// 16-byte loads, fp32 math.  The kernel is one latency chain per wave (loads -> reduce -> reduce -> stores) on data the previous GEMM left in
+// L2 / Infinity Cache.
+template <typename T, int NCH, bool X32, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const idmvton_layernorm_args a) {
     typedef typename VT<T>::v8 v8;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= a.rows) return;
     const int nchunk = a.C >> 3;
-    const T* x = (const T*)a.x + (size_t)row * a.ldx;
-    const float* xf = (const float*)a.x + (size_t)row * a.ldx;      // X32: the fp32 residual stream
     const T* gamma = (const T*)a.gamma;
     const T* beta = (const T*)a.beta;
     v8 gm[NCH], bt_[NCH];                                // gamma / beta issued with the row loads: their L2 latency used to sit behind
-#pragma unroll                                           // the two reductions, in front of the stores (this kernel is one latency chain per wave)
+#pragma unroll                                           // the two reductions, in front of the stores
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) { gm[i] = *(const v8*)(gamma + c * 8); bt_[i] = *(const v8*)(beta + c * 8); }
     }
-    float v[NCH][8];
-    float s = 0.f;
+    float v[RPW][NCH][8];
+    float s[RPW];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-            if constexpr (X32) {
-                const float4 t0 = *(const float4*)(xf + c * 8), t1 = *(const float4*)(xf + c * 8 + 4);
-                v[i][0] = t0.x; v[i][1] = t0.y; v[i][2] = t0.z; v[i][3] = t0.w;
-                v[i][4] = t1.x; v[i][5] = t1.y; v[i][6] = t1.z; v[i][7] = t1.w;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < a.rows ? row0 + r : a.rows - 1;       // a ragged last pair recomputes the last row (same values, same address)
+        const T* x = (const T*)a.x + (size_t)row * a.ldx;
+        const float* xf = (const float*)a.x + (size_t)row * a.ldx;      // X32: the fp32 residual stream
+        s[r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[i][j];
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                if constexpr (X32) {
+                    const float4 t0 = *(const float4*)(xf + c * 8), t1 = *(const float4*)(xf + c * 8 + 4);
+                    v[r][i][0] = t0.x; v[r][i][1] = t0.y; v[r][i][2] = t0.z; v[r][i][3] = t0.w;
+                    v[r][i][4] = t1.x; v[r][i][5] = t1.y; v[r][i][6] = t1.z; v[r][i][7] = t1.w;
+                } else {
+                    const v8 t = *(const v8*)(x + c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[r][i][j] = (float)t[j];
+                }
             } else {
-                const v8 t = *(const v8*)(x + c * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+                for (int j = 0; j < 8; ++j) v[r][i][j] = 0.f;
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
     }
-    const float mean = wave_sum_dpp(s) / (float)a.C;
-    float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[r] += v[r][i][j];
+    float mean[RPW], q[RPW], rstd[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) mean[r] = wave_sum_dpp(s[r]) / (float)a.C;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[r][i][j] - mean[r]; q[r] += d * d; }
+            }
         }
     }
-    const float rstd = rsqrtf(wave_sum_dpp(q) / (float)a.C + a.eps);
-    T* y = (T*)a.y + (size_t)row * a.ldy;
-    T* y2 = a.y2 ? (T*)a.y2 + (size_t)row * a.ldy2 : nullptr;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-            v8 o;
+    for (int r = 0; r < RPW; ++r) rstd[r] = rsqrtf(wave_sum_dpp(q[r]) / (float)a.C + a.eps);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (T)((v[i][j] - mean) * rstd * (float)gm[i][j] + (float)bt_[i][j]);
-            *(v8*)(y + c * 8) = o;
-            if (y2) *(v8*)(y2 + c * 8) = o;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < a.rows ? row0 + r : a.rows - 1;
+        T* y = (T*)a.y + (size_t)row * a.ldy;
+        T* y2 = a.y2 ? (T*)a.y2 + (size_t)row * a.ldy2 : nullptr;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                v8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (T)((v[r][i][j] - mean[r]) * rstd[r] * (float)gm[i][j] + (float)bt_[i][j]);
+                *(v8*)(y + c * 8) = o;
+                if (y2) *(v8*)(y2 + c * 8) = o;
+            }
         }
     }
 }
 
+template <typename T, bool X32, int RPW>
+static void launch_ln_n(const idmvton_layernorm_args& a, hipStream_t st) {
+    const dim3 grid((a.rows + 4 * RPW - 1) / (4 * RPW)), block(256);
+    const int nch = ((a.C >> 3) + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1, X32, RPW>), grid, block, 0, st, a);
+    else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2, X32, RPW>), grid, block, 0, st, a);
+    else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3, X32, RPW>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<T, 4, X32, RPW>), grid, block, 0, st, a);
+}
+
 template <typename T>
 static int launch_ln(const idmvton_layernorm_args& a, hipStream_t st) {
-    const dim3 grid((a.rows + 3) / 4), block(256);
-    const int nch = ((a.C >> 3) + 63) / 64;
-    if (a.x_f32) {
-        if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1, true>), grid, block, 0, st, a);
-        else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2, true>), grid, block, 0, st, a);
-        else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((layernorm_kernel<T, 4, true>), grid, block, 0, st, a);
-    } else if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<T, 1, false>), grid, block, 0, st, a);
-    else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<T, 2, false>), grid, block, 0, st, a);
-    else if (nch == 3) hipLaunchKernelGGL((layernorm_kernel<T, 3, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((layernorm_kernel<T, 4, false>), grid, block, 0, st, a);
+    // one row per wave.  Two rows per wave (both rows' loads in flight before the first reduction) measured the same or slower on every shape
+    // of the loop (profiles/r04_ln_rows_per_wave.log: 8.4-8.6 us at 3072 x 1280 either way, 10.5 vs 11.8 us at 9216 x 1280): the launch is a
+    // latency floor -- dispatch, one L2 / Infinity-Cache round trip, two wave reductions, the store drain -- not a bandwidth problem
+    if (a.x_f32) launch_ln_n<T, true, 1>(a, st);
+    else launch_ln_n<T, false, 1>(a, st);
     CHECK_LAUNCH("layernorm");
     return IDMVTON_OK;
 }
@@ -323,8 +349,9 @@ extern "C" int idmvton_groupnorm(const idmvton_groupnorm_args* a, void* stream) 
 // ------------------------------------------------------------------------------------------------ row softmax
 // In-place softmax(scale * x) over rows of n elements (n % 8 == 0), fp32 statistics, one workgroup per row.
 // Used by the VAE mid-block attention (single head, d = 512: unet_block_hacked_tryon.py:585-597, upcast_softmax=True).
+// nv = columns that take part (<= n); columns nv..n-1 are written as 0 (key padding up to the next GEMM's K granule)
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, float scale, int nv) {
     typedef typename VT<T>::v8 v8;
     __shared__ float red[8];
     T* row = x + (size_t)blockIdx.x * ld;
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, 
     for (int c = threadIdx.x; c < nchunk; c += 256) {
         const v8 t = *(const v8*)(row + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)t[j]);
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, c * 8 + j < nv ? (float)t[j] : -3.0e38f);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, 
     for (int c = threadIdx.x; c < nchunk; c += 256) {
         const v8 t = *(const v8*)(row + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f(((float)t[j] - mx) * sl);
+        for (int j = 0; j < 8; ++j) s += c * 8 + j < nv ? __builtin_amdgcn_exp2f(((float)t[j] - mx) * sl) : 0.f;
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
@@ -356,14 +383,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n, int ld, 
         const v8 t = *(const v8*)(row + c * 8);
         v8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (T)(__builtin_amdgcn_exp2f(((float)t[j] - mx) * sl) * inv);
+        for (int j = 0; j < 8; ++j) o[j] = (T)(c * 8 + j < nv ? __builtin_amdgcn_exp2f(((float)t[j] - mx) * sl) * inv : 0.f);
         *(v8*)(row + c * 8) = o;
     }
 }
 
 // Split-precision form: logits fp32 [rows][ld] (read three times from L2), probabilities out as the pair [hi (n) | lo (n)] of T.
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* x, int n, int ld, float scale, T* y, int ldy) {
+__global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* x, int n, int ld, float scale, T* y, int ldy, int nv) {
     typedef typename VT<T>::v8 v8;
     __shared__ float red[8];
     const float* row = x + (size_t)blockIdx.x * ld;
@@ -373,7 +400,9 @@ __global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* x,
     float mx = -3.0e38f;
     for (int c = threadIdx.x; c < nchunk; c += 256) {
         const float4 t0 = *(const float4*)(row + c * 8), t1 = *(const float4*)(row + c * 8 + 4);
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(t0.x, t0.y), fmaxf(t0.z, t0.w)), fmaxf(fmaxf(t1.x, t1.y), fmaxf(t1.z, t1.w))));
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, c * 8 + j < nv ? v[j] : -3.0e38f);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -386,7 +415,7 @@ __global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* x,
         const float4 t0 = *(const float4*)(row + c * 8), t1 = *(const float4*)(row + c * 8 + 4);
         const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f((v[j] - mx) * sl);
+        for (int j = 0; j < 8; ++j) s += c * 8 + j < nv ? __builtin_amdgcn_exp2f((v[j] - mx) * sl) : 0.f;
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* x,
         v8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float p = __builtin_amdgcn_exp2f((v[j] - mx) * sl) * inv;
+            const float p = c * 8 + j < nv ? __builtin_amdgcn_exp2f((v[j] - mx) * sl) * inv : 0.f;
             hi[j] = (T)p;
             lo[j] = (T)(p - (float)hi[j]);
         }
@@ -413,15 +442,17 @@ extern "C" int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream)
     CHECK_ARG(a->rows > 0 && a->n > 0 && a->n % 8 == 0 && (a->y_split || a->ld % 8 == 0) && a->ld >= a->n && ((uintptr_t)a->x & 15) == 0,
               IDMVTON_E_SHAPE, "softmax_rows: rows=%d n=%d ld=%d", a->rows, a->n, a->ld);
     const dim3 grid(a->rows), block(256);
+    CHECK_ARG(a->n_valid >= 0 && a->n_valid <= a->n, IDMVTON_E_SHAPE, "softmax_rows: n_valid=%d n=%d", a->n_valid, a->n);
+    const int nv = a->n_valid ? a->n_valid : a->n;
     if (a->y_split) {
         CHECK_ARG(a->ldy % 8 == 0 && a->ldy >= 2 * a->n && ((uintptr_t)a->y_split & 15) == 0 && a->ld % 4 == 0, IDMVTON_E_SHAPE, "softmax_rows: y_split ldy=%d n=%d", a->ldy, a->n);
-        if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_split_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const float*)a->x, a->n, a->ld, a->scale, (bf16_t*)a->y_split, a->ldy);
-        else hipLaunchKernelGGL((softmax_rows_split_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (const float*)a->x, a->n, a->ld, a->scale, (f16_t*)a->y_split, a->ldy);
+        if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_split_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const float*)a->x, a->n, a->ld, a->scale, (bf16_t*)a->y_split, a->ldy, nv);
+        else hipLaunchKernelGGL((softmax_rows_split_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (const float*)a->x, a->n, a->ld, a->scale, (f16_t*)a->y_split, a->ldy, nv);
         CHECK_LAUNCH("softmax_rows");
         return IDMVTON_OK;
     }
-    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)a->x, a->n, a->ld, a->scale);
-    else hipLaunchKernelGGL((softmax_rows_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (f16_t*)a->x, a->n, a->ld, a->scale);
+    if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)a->x, a->n, a->ld, a->scale, nv);
+    else hipLaunchKernelGGL((softmax_rows_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (f16_t*)a->x, a->n, a->ld, a->scale, nv);
     CHECK_LAUNCH("softmax_rows");
     return IDMVTON_OK;
 }

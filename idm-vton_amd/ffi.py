@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_hip.so")   # override: A/B of library builds
 
 F16, BF16, F32, F8E4M3 = 0, 1, 2, 3
-EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
+EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU, EPI_XATTN = 0, 1, 2, 3, 4
 ATTN_SELF, ATTN_CROSS = 0, 1
 IO_RES_F32, IO_OUT_F32, IO_BIAS_F32 = 1, 2, 4
 GN_X_F32, GN_Y_SPLIT, GN_AFFINE_F32 = 1, 2, 4
@@ -26,13 +26,18 @@ class Seg(C.Structure):
     _fields_ = [("ptr", vp), ("bytes", u32), ("pitch", i32), ("coff", i32), ("len", i32), ("dy", i32), ("dx", i32)]
 
 
+class XAttn(C.Structure):
+    _fields_ = [("nseg", i32), ("k", vp * 2), ("ldk", i32 * 2), ("k_rows", i32 * 2), ("vt", vp * 2), ("ldvt", i32 * 2), ("nk", i32 * 2),
+                ("tokens", i32), ("ip_scale", f32)]
+
+
 class GemmConvArgs(C.Structure):
     _fields_ = [("dtype", i32), ("w", vp), ("N", i32), ("Ktot", i32), ("nseg", i32), ("seg", Seg * MAX_SEG),
                 ("M", i32), ("Ho", i32), ("Wo", i32), ("Hi", i32), ("Wi", i32), ("stride", i32), ("ups", i32),
                 ("out", vp), ("ldo", i32), ("bias", vp), ("rowbias", vp), ("rowbias_ld", i32),
                 ("rows_per_group", i32), ("res", vp), ("ldr", i32), ("mode", i32), ("vt", vp), ("vt_n0", i32),
                 ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("io_flags", i32), ("rowstats_out", vp), ("rowstats_final", vp), ("rowstats_counter", vp), ("rowstats_eps", f32),
-                ("ln_rowstats", vp), ("ln_colvec", vp),
+                ("ln_rowstats", vp), ("ln_colvec", vp), ("xattn", C.POINTER(XAttn)),
                 ("colscale_n", i32), ("colscale", f32)]
 
 
@@ -88,7 +93,7 @@ class QuantF8Args(C.Structure):
 
 
 class SoftmaxArgs(C.Structure):
-    _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32), ("y_split", vp), ("ldy", i32)]
+    _fields_ = [("dtype", i32), ("rows", i32), ("n", i32), ("ld", i32), ("x", vp), ("scale", f32), ("y_split", vp), ("ldy", i32), ("n_valid", i32)]
 
 
 class SplitArgs(C.Structure):
@@ -100,7 +105,7 @@ STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_
            "idmvton_pack_input_args": PackInputArgs, "idmvton_cfg_step_args": CfgStepArgs,
            "idmvton_layout_args": LayoutArgs, "idmvton_vae_sample_args": VaeSampleArgs, "idmvton_softmax_args": SoftmaxArgs,
            "idmvton_attn_small_args": AttnSmallArgs, "idmvton_attn_f8_args": AttnF8Args, "idmvton_quant_f8_args": QuantF8Args,
-           "idmvton_split_args": SplitArgs}
+           "idmvton_split_args": SplitArgs, "idmvton_xattn": XAttn}
 
 # every symbol include/idmvton_hip.h declares
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",

@@ -88,12 +88,16 @@ class SegSpec:
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, quick_gelu=False, vt=None,
-              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, rowstats_out=None, ln=None):
+              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, rowstats_out=None, ln=None,
+              xattn=None):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
     fp32 residual stream: a float32 `res` is read as fp32; out_f32=True (or a float32 `out`) writes fp32 (io_flags).
     LayerNorm folded into the GEMMs around it: rowstats_out = a RowStats on the PRODUCER of a hidden state (its tiles emit (sum, sum of
     squares) per 32-column group of the stored values, the last tile to finish a row tile folds them to (rstd, -rstd*mean) per row);
     ln = (that RowStats, colvec fp32 [2][N] {s, c}) on the CONSUMER, whose weights carry gamma (see ln_fold_weights).
+    xattn = dict(segs=[dict(k=, vt=, nk=, ldk=, ldvt=, k_rows=)] * (1 | 2), tokens=rows per batch element, ip_scale=): the GEMM is a
+    cross-attention's query projection and its epilogue is the attention (include/idmvton_hip.h, IDMVTON_EPI_XATTN); w's rows in
+    accumulator order (xattn_q_weight()).
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
     kernel's key order (see key_order()), False as a plain transpose."""
     a = ffi.GemmConvArgs()
@@ -130,6 +134,14 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.res = _ptr(res)
     a.ldr = (ldr if ldr is not None else (res.stride(-2) if res is not None else 0))
     a.mode = ffi.EPI_GEGLU if geglu else (ffi.EPI_GELU if gelu else (ffi.EPI_QUICKGELU if quick_gelu else ffi.EPI_NONE))
+    xa, xflops = None, 0.0
+    if xattn is not None:
+        xa = ffi.XAttn()
+        xa.nseg, xa.tokens, xa.ip_scale = len(xattn["segs"]), xattn["tokens"], xattn.get("ip_scale", 1.0)
+        for i, sg in enumerate(xattn["segs"]):
+            xa.k[i], xa.vt[i], xa.ldk[i], xa.ldvt[i], xa.nk[i], xa.k_rows[i] = _ptr(sg["k"]), _ptr(sg["vt"]), sg["ldk"], sg["ldvt"], sg["nk"], sg["k_rows"]
+            xflops += 4.0 * M * N * sg["nk"]
+        a.mode, a.xattn = ffi.EPI_XATTN, C.pointer(xa)
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.colscale_n, a.colscale = colscale_n, colscale
@@ -145,7 +157,7 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
         a.ln_rowstats, a.ln_colvec = _ptr(rs.final), _ptr(colvec)
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
-        RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt)))
+        RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt, xa, xattn)))
     seen, xbytes = set(), 0                               # algorithmic bytes: every distinct operand tensor once
     for sg in segs:
         if sg.t.data_ptr() not in seen:
@@ -153,8 +165,14 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
             xbytes += sg.t.numel() * sg.t.element_size()
     esz = w.element_size()
     obytes = (M * (N // 2 if geglu else N)) * (out.element_size() if out is not None else esz) + (M * N * res.element_size() if res is not None else 0)
-    _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot, bytes_=float(xbytes + N * Ktot * esz + obytes))
+    _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot + xflops, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
+
+
+def xattn_q_weight(w):
+    """attn2.to_q weight [heads*64][K] -> rows in the ACCUMULATOR ORDER the fused cross-attention epilogue contracts in: inside every group of
+    16 output channels, bits 2 and 3 of the channel index swapped (the same involution as key_order_index)."""
+    return w.index_select(0, key_order_index(w.shape[0], w.device)).contiguous()
 
 
 class RowStats:
@@ -389,20 +407,22 @@ def vae_sample(moments_nhwc, noise, scale, out=None):
     return out
 
 
-def softmax_rows(x, scale):
-    """In-place softmax(scale * x) over the last dim of a 2-D tensor."""
+def softmax_rows(x, scale, n_valid=0):
+    """In-place softmax(scale * x) over the last dim of a 2-D tensor; n_valid: over its first n_valid columns, the rest set to 0."""
     a = ffi.SoftmaxArgs()
     a.dtype, a.rows, a.n, a.ld = _dt(x), x.shape[0], x.shape[1], x.stride(0)
-    a.x, a.scale = _ptr(x), scale
+    a.x, a.scale, a.n_valid = _ptr(x), scale, n_valid
     _call("idmvton_softmax_rows", a)
     return x
 
 
-def softmax_rows_split(x, scale, dtype):
-    """softmax(scale * x) over the last dim of an fp32 2-D tensor -> the pair [rows][2n] = [hi | lo] of `dtype` (x is left as it is)."""
+def softmax_rows_split(x, scale, dtype, n_valid=0):
+    """softmax(scale * x) over the last dim of an fp32 2-D tensor -> the pair [rows][2n] = [hi | lo] of `dtype` (x is left as it is);
+    n_valid: over the first n_valid columns, the rest 0."""
     rows, n = x.shape
     out = torch.empty((rows, 2 * n), dtype=dtype, device=x.device)
     a = ffi.SoftmaxArgs()
+    a.n_valid = n_valid
     a.dtype, a.rows, a.n, a.ld = _dt(out), rows, n, x.stride(0)
     a.x, a.scale, a.y_split, a.ldy = _ptr(x), scale, _ptr(out), out.stride(0)
     _call("idmvton_softmax_rows", a, bytes_=float(rows * n * (3 * 4 + 2 * out.element_size())))

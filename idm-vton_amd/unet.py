@@ -11,6 +11,7 @@ topology walk, same state-dict keys, every arithmetic op a C-ABI call (ops.py). 
   * GarmentNet stops after its last exported norm1 (everything after it is dead: unet_hacked_garmnet.py:1267-1284).
 """
 import math
+import os
 
 import torch
 
@@ -47,7 +48,8 @@ class _Conv:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, fuse_ln=False, attn_fp8=False):
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, fuse_ln=False, attn_fp8=False,
+                 fuse_xattn=True):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         # stream_f32: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
         # attentionhacked_tryon.py:348,384,412) stays fp32 from proj_in to the last block's ff.net.2, whose output is rounded once
@@ -70,6 +72,9 @@ class HipUNet:
         # the block-scaled MFMA (csrc/attention_f8.hip); q, k, v are quantised with power-of-two scales 2^eq, 2^ek, 2^ev right after the
         # QKV projection.  Cross-attention (93 keys) and everything else stay 16-bit.  6e-2 .. 1e-1 max-rel per attention output (e4m3: 3 mantissa bits).
         self.attn_fp8 = bool(attn_fp8)
+        # fuse_xattn: attn2.to_q -> cross-attention (77 text [+ 16 image] keys) as ONE launch, the attention being the projection's epilogue
+        # (csrc/xattn.cuh).  Same arithmetic as the two launches (q rounded once to the storage type, fp32 logits and softmax, P rounded for P.V)
+        self.fuse_xattn = bool(fuse_xattn) and os.environ.get("IDMVTON_FUSE_XATTN", "1") != "0"
         self.f8_exp = (2, 2, 2)
         self.topo = unet_topology(cfg)
         sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items() if not k.startswith("encoder_hid_proj.")}
@@ -182,13 +187,13 @@ class HipUNet:
         text: [B][77][xd]; ip: [B][16][xd] image tokens (TryonNet).  Rows are padded to a multiple of 16 with zeros."""
         dt, dev = self.dtype, self.device
         B, nt, xd = text.shape
-        rt = ops.round16(nt)                                 # key-order V^T needs multiples of 16
+        rt = (nt + 31) // 32 * 32                            # key-order V^T needs multiples of 16; the fused cross-attention reads K in 32-row blocks
         tpad = torch.zeros(B, rt, xd, dtype=dt, device=dev)
         tpad[:, :nt] = text.to(dev, dt)
         ctx = dict(B=B, nt=nt, rt=rt, kv={})
         if ip is not None:
             ni = ip.shape[1]
-            ri = ops.round16(ni)
+            ri = (ni + 31) // 32 * 32
             ipad = torch.zeros(B, ri, xd, dtype=dt, device=dev)
             ipad[:, :ni] = ip.to(dev, dt)
             ctx.update(ni=ni, ri=ri)
@@ -296,19 +301,29 @@ class HipUNet:
         f32 = hs.dtype == torch.float32                          # the fp32 residual stream (see __init__)
         hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
         # cross attention
-        if fuse:                                                 # norm2 folded into attn2.to_q
-            q2 = ops.linear(hs, blk["q2_w"], ln=(rs, blk["q2_cv"]))
-        else:
-            n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
-            q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
         kv = ctx["kv"][p]
-        att2 = torch.empty(M, C, dtype=dt, device=dev)
         seg_t = dict(k=kv["kt"], vt=kv["vtt"], nk=ctx["nt"], ldk=C, ldvt=ctx["rt"], k_rows=ctx["rt"])
-        if self.tryon:
-            seg_i = dict(k=kv["ki"], vt=kv["vti"], nk=ctx["ni"], ldk=C, ldvt=ctx["ri"], k_rows=ctx["ri"])
-            ops.attention(q2, att2, [seg_t, seg_i], heads, mode=ffi.ATTN_CROSS, ip_scale=self.ip_scale, B=B, Nq=N, ldq=C, ldo=C)
+        xsegs = [seg_t] + ([dict(k=kv["ki"], vt=kv["vti"], nk=ctx["ni"], ldk=C, ldvt=ctx["ri"], k_rows=ctx["ri"])] if self.tryon else [])
+        # (not for the timestep-batched GarmentNet at the 1280-channel level: at M = 9216 the plain projection runs on the 256x256 tile at twice
+        #  the rate of the 128-column tiles the fused form needs -- 55 us for the two launches against 60 fused, profiles/r04_xattn_probe_*.log)
+        if self.fuse_xattn and not fuse and N % 32 == 0 and not (C >= 1280 and M >= 8192) and \
+                all(sg["nk"] <= 96 and sg["k_rows"] >= (sg["nk"] + 31) // 32 * 32 for sg in xsegs):
+            # attn2.to_q with the cross-attention as its epilogue (csrc/xattn.cuh): q never leaves the registers, no attention launch
+            if "q2_xw" not in blk:
+                blk["q2_xw"] = ops.xattn_q_weight(sd[p + ".attn2.to_q.weight"])
+            n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+            att2 = ops.linear(n2, blk["q2_xw"], xattn=dict(segs=xsegs, tokens=N, ip_scale=self.ip_scale))
         else:
-            ops.attention(q2, att2, [seg_t], heads, B=B, Nq=N, ldq=C, ldo=C)
+            if fuse:                                             # norm2 folded into attn2.to_q
+                q2 = ops.linear(hs, blk["q2_w"], ln=(rs, blk["q2_cv"]))
+            else:
+                n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+                q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
+            att2 = torch.empty(M, C, dtype=dt, device=dev)
+            if self.tryon:
+                ops.attention(q2, att2, xsegs, heads, mode=ffi.ATTN_CROSS, ip_scale=self.ip_scale, B=B, Nq=N, ldq=C, ldo=C)
+            else:
+                ops.attention(q2, att2, xsegs, heads, B=B, Nq=N, ldq=C, ldo=C)
         hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
         # feed-forward (GEGLU fused into the first GEMM's epilogue)
         if fuse:                                                 # norm3 folded into the GEGLU projection

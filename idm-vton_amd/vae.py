@@ -175,9 +175,24 @@ class HipVAE:
         # GEMMs are then softmax logits of O(1) magnitude instead of raw 512-term dot products
         q = ops.linear(t, sd[p + ".to_q.weight"], bias=sd[p + ".to_q.bias"], colscale_n=C, colscale=C ** -0.5)
         k = ops.linear(t, sd[p + ".to_k.weight"], bias=sd[p + ".to_k.bias"])
+        o = torch.empty(B * N, C, dtype=dt, device=dev)
+        if N % 64:
+            # a token count that is not a multiple of the GEMM's K granule (latent H*W of an odd size, e.g. 33 x 25): keys padded to Np rows of
+            # zeros, the softmax runs over the first N columns and writes 0 into the rest, V^T zero-padded the same way (torch glue: rare path)
+            Np = (N + 63) // 64 * 64
+            v = ops.linear(t, sd[p + ".to_v.weight"], bias=sd[p + ".to_v.bias"])
+            for b in range(B):
+                kp = torch.zeros(Np, C, dtype=dt, device=dev)
+                kp[:N] = k[b * N:(b + 1) * N]
+                vtp = torch.zeros(C, Np, dtype=dt, device=dev)
+                vtp[:, :N] = v[b * N:(b + 1) * N].t()
+                s = ops.linear(q[b * N:(b + 1) * N], kp)                         # [N][Np]
+                ops.softmax_rows(s, 1.0, n_valid=N)
+                ops.linear(s, vtp, out=o[b * N:(b + 1) * N])
+            out = ops.linear(o, sd[p + ".to_out.0.weight"], bias=sd[p + ".to_out.0.bias"], res=x.reshape(B * N, C))
+            return out.view(B, N, C)
         vt = torch.empty(B, C, N, dtype=dt, device=dev)
         ops.linear(t, sd[p + ".to_v.weight"], bias=sd[p + ".to_v.bias"], vt=vt, vt_n0=0, vt_tokens=N, vt_perm=False)
-        o = torch.empty(B * N, C, dtype=dt, device=dev)
         for b in range(B):
             s = ops.linear(q[b * N:(b + 1) * N], k[b * N:(b + 1) * N])          # [N][N] scores
             ops.softmax_rows(s, 1.0)
@@ -298,18 +313,22 @@ class HipVAE:
         o = torch.empty(B * N, C, dtype=torch.float32, device=self.device)
         # query rows in chunks: the probability pair [rows][2N] is addressed through a 32-bit buffer descriptor (< 2 GiB): all 12288 rows at
         # once at 768x1024, 16384 of the 24576 at 1024x1536
-        qc = max(256, min(N, (2 ** 31 - 1) // (4 * N) // 256 * 256))
+        Np = (N + 63) // 64 * 64                             # keys padded (zero rows) to the K granule of the P.V product; == N at the usual sizes
+        qc = max(256, min(N, (2 ** 31 - 1) // (4 * Np) // 256 * 256))
         for b in range(B):
-            k3 = ops.split(k[b * N:(b + 1) * N], self.PDT, ffi.SPLIT_W3)
-            vt3 = ops.split(v[b * N:(b + 1) * N], self.PDT, ffi.SPLIT_W3T)                                      # [C][3N]
+            kb, vb = k[b * N:(b + 1) * N], v[b * N:(b + 1) * N]
+            if Np != N:
+                kb, vb = torch.cat([kb, kb.new_zeros(Np - N, C)]), torch.cat([vb, vb.new_zeros(Np - N, C)])
+            k3 = ops.split(kb, self.PDT, ffi.SPLIT_W3)                                                          # [Np][3C]
+            vt3 = ops.split(vb, self.PDT, ffi.SPLIT_W3T)                                                        # [C][3Np]
             for r0 in range(0, N, qc):
                 sl = slice(b * N + r0, b * N + min(r0 + qc, N))
                 n = sl.stop - sl.start
                 qp = self._pair(q[sl])
-                s = ops.gemm_conv([ops.SegSpec(qp, 0, 2 * C), ops.SegSpec(qp, 0, C)], k3, n, out_f32=True)      # [n][N] logits, 3-term product
-                pp = ops.softmax_rows_split(s, 1.0, self.PDT)
+                s = ops.gemm_conv([ops.SegSpec(qp, 0, 2 * C), ops.SegSpec(qp, 0, C)], k3, n, out_f32=True)      # [n][Np] logits, 3-term product
+                pp = ops.softmax_rows_split(s, 1.0, self.PDT, n_valid=0 if Np == N else N)
                 del s
-                ops.gemm_conv([ops.SegSpec(pp, 0, 2 * N), ops.SegSpec(pp, 0, N)], vt3, n, out=o[sl])
+                ops.gemm_conv([ops.SegSpec(pp, 0, 2 * Np), ops.SegSpec(pp, 0, Np)], vt3, n, out=o[sl])
                 del pp
             del k3, vt3
         out = self._plin(self._pair(o), p + ".to_out.0", res=x.reshape(B * N, C))

@@ -63,7 +63,22 @@ typedef struct {
 } idmvton_seg;
 
 enum { IDMVTON_EPI_NONE = 0, IDMVTON_EPI_GEGLU = 1, IDMVTON_EPI_GELU = 2 /* gelu_erf(acc+bias+rowbias) then +res */,
-       IDMVTON_EPI_QUICKGELU = 3 /* x*sigmoid(1.702x): CLIP-L text MLP (transformers hidden_act "quick_gelu") */ };
+       IDMVTON_EPI_QUICKGELU = 3 /* x*sigmoid(1.702x): CLIP-L text MLP (transformers hidden_act "quick_gelu") */,
+       IDMVTON_EPI_XATTN = 4 /* the GEMM is attn2.to_q and its epilogue IS the cross-attention: see idmvton_xattn */ };
+/* mode IDMVTON_EPI_XATTN: out = softmax(q k_0^T / 8) v_0 [+ ip_scale * softmax(q k_1^T / 8) v_1], q = X . W^T never written to memory.
+ * Replaces attn2 of every BasicTransformerBlock: to_q + the two SDPAs + their sum (ip_adapter/attention_processor.py:1943,1970-1995; GarmentNet:
+ * diffusers Attention with the text keys only, nseg = 1) in ONE launch -- the step-invariant K / V^T tables (77 text + 16 image tokens) are read
+ * by the epilogue straight from memory.  Head h = columns [64h, 64h + 64) of W's N outputs.  W's rows must be in the ACCUMULATOR ORDER: inside every
+ * group of 16 output channels, bits 2 and 3 of the channel index swapped (row p of W = to_q row (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)); K
+ * and V^T are the tables idmvton_attn_fwd takes (K [B][k_rows][ldk], V^T [B][N][ldvt] in key order).  Keys >= nk are masked; rows nk..k_rows-1 of K
+ * must be readable (k_rows >= round32(nk)).  tokens = GEMM rows per batch element (a multiple of 32).  No bias / residual / colscale. */
+typedef struct {
+    int32_t nseg;
+    const void* k[2]; int32_t ldk[2]; int32_t k_rows[2];
+    const void* vt[2]; int32_t ldvt[2];
+    int32_t nk[2];               /* <= 96 */
+    int32_t tokens; float ip_scale;
+} idmvton_xattn;
 enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2, IDMVTON_IO_BIAS_F32 = 4 };
 typedef struct {
     int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type; see io_flags) */
@@ -113,6 +128,7 @@ typedef struct {
        normalised copy of x in HBM.  All NULL = off. */
     float* rowstats_out; float* rowstats_final; uint32_t* rowstats_counter; float rowstats_eps;
     const float* ln_rowstats; const float* ln_colvec;
+    const idmvton_xattn* xattn;  /* mode IDMVTON_EPI_XATTN only (host pointer, read during the call) */
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */
@@ -293,6 +309,8 @@ typedef struct {
     void* x; float scale;
     void* y_split; int32_t ldy;  /* NULL: in place, x of `dtype`.  Else x holds fp32 [rows][ld] (read only) and the probabilities are written as the
                                     pair [rows][ldy] = [hi (n) | lo (n)] of `dtype`: the A operand of the split-precision P.V product */
+    int32_t n_valid;             /* 0 = n.  Else the softmax runs over the first n_valid (<= n) columns and columns n_valid..n-1 are written as 0:
+                                    a key count that is not a multiple of 64 (latent H*W of an odd size) is padded up to the GEMM's K granule */
 } idmvton_softmax_args;
 int idmvton_softmax_rows(const idmvton_softmax_args* a, void* stream);
 

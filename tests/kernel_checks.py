@@ -404,6 +404,39 @@ def check_attn_cross(B, heads, N, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, 
     return relerr(out, ref)
 
 
+def check_xattn_fused(B, heads, N, K, dtype, dev, n_text=77, n_ip=16, ip_scale=1.0, tile_hint=0, seed=0):
+    """attn2.to_q with the cross-attention as its epilogue (IDMVTON_EPI_XATTN) against fp32: q = x Wq^T, softmax(q k_t^T / 8) v_t + ip_scale *
+    softmax(q k_i^T / 8) v_i per head; and against the two-launch form it replaces (same roundings: equal up to summation order)."""
+    from idm_vton_amd import ffi, ops
+    C = heads * 64
+    M = B * N
+    x = _r(M, K, dtype=dtype, dev=dev, seed=seed)
+    wq = _r(C, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 1)
+    segs, refs = [], []
+    q = (x.float() @ wq.float().t()).to(dtype).float().view(B, N, heads, 64).transpose(1, 2)          # q is rounded once to the storage type
+    out_ref = torch.zeros(B, heads, N, 64, device=dev)
+    for i, nk in enumerate([n_text] + ([n_ip] if n_ip else [])):
+        rows = (nk + 31) // 32 * 32
+        k = torch.zeros(B, rows, C, dtype=dtype, device=dev)
+        k[:, :nk] = _r(B, nk, C, dtype=dtype, dev=dev, seed=seed + 2 + i)
+        v = _r(B, nk, C, dtype=dtype, dev=dev, seed=seed + 5 + i)
+        vt = torch.zeros(B, C, rows, dtype=dtype, device=dev)
+        vt[:, :, :nk] = v.transpose(1, 2)
+        segs.append(dict(k=k, vt=ops.key_order(vt), nk=nk, ldk=C, ldvt=rows, k_rows=rows))
+        kk = k[:, :nk].float().view(B, nk, heads, 64).transpose(1, 2)
+        vv = v.float().view(B, nk, heads, 64).transpose(1, 2)
+        out_ref += (ip_scale if i == 1 else 1.0) * F.scaled_dot_product_attention(q, kk, vv)
+    ref = out_ref.transpose(1, 2).reshape(M, C)
+    fused = ops.linear(x, ops.xattn_q_weight(wq), xattn=dict(segs=segs, tokens=N, ip_scale=ip_scale), tile_hint=tile_hint)
+    q2 = ops.linear(x, wq)
+    two = torch.empty(M, C, dtype=dtype, device=dev)
+    if n_ip:
+        ops.attention(q2, two, segs, heads, mode=ffi.ATTN_CROSS, ip_scale=ip_scale, B=B, Nq=N, ldq=C, ldo=C)
+    else:
+        ops.attention(q2, two, segs, heads, B=B, Nq=N, ldq=C, ldo=C)
+    return max(relerr(fused, ref), relerr(fused, two.float()))
+
+
 def check_attn_small(B, heads, L, d, dtype, dev, causal, Lq=None, seed=0, scale=1.0):
     """idmvton_attn_small (CLIP towers): fused-QKV layout, any even head_dim <= 128, optional causal mask."""
     from idm_vton_amd import ops
@@ -597,14 +630,29 @@ def check_gn_precise(B, HW, Cc, dev, groups=32, silu=True, seed=0):
     return _relerr64(out[..., :Cc].double() + out[..., Cc:].double(), ref)
 
 
-def check_softmax_split(rows, n, dev, seed=0):
+def check_softmax_split(rows, n, dev, seed=0, n_valid=0):
     from idm_vton_amd import ops
     x = _r(rows, n, dtype=torch.float32, dev=dev, scale=3.0, seed=seed)
     keep = x.clone()
-    out = ops.softmax_rows_split(x, 0.7, torch.bfloat16)
-    ref = torch.softmax(0.7 * x.double(), dim=-1)
+    out = ops.softmax_rows_split(x, 0.7, torch.bfloat16, n_valid=n_valid)
+    nv = n_valid or n
+    ref = torch.zeros(rows, n, dtype=torch.float64, device=dev)
+    ref[:, :nv] = torch.softmax(0.7 * x[:, :nv].double(), dim=-1)
     assert torch.equal(x, keep)
-    return _relerr64(out[:, :n].double() + out[:, n:].double(), ref)
+    tail = float(out[:, nv:n].abs().max() + out[:, n + nv:].abs().max()) if nv < n else 0.0      # padded columns are exact zeros
+    return max(_relerr64(out[:, :n].double() + out[:, n:].double(), ref), tail)
+
+
+def check_softmax_rows(rows, n, dtype, dev, n_valid=0, seed=0):
+    """In-place row softmax (VAE mid-block attention, 16-bit path); n_valid: the padded-key form."""
+    from idm_vton_amd import ops
+    x = _r(rows, n, dtype=dtype, dev=dev, scale=3.0, seed=seed)
+    nv = n_valid or n
+    ref = torch.zeros(rows, n, dtype=torch.float32, device=dev)
+    ref[:, :nv] = torch.softmax(0.7 * x[:, :nv].float(), dim=-1)
+    ops.softmax_rows(x, 0.7, n_valid=n_valid)
+    tail = float(x[:, nv:].float().abs().max()) if nv < n else 0.0
+    return max(relerr(x, ref), tail)
 
 
 def check_plin(M, N, K, dev, exact_w=False, res=True, seed=0):
@@ -702,7 +750,7 @@ def _hint(variant, bn, bm):
     return (variant << 28) | (bn << 16) | bm
 
 
-RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"), (_hint(5, 256, 258), "h5f2"), (_hint(5, 256, 259), "h5f3"), (_hint(5, 256, 260), "h5f4"),
+RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
               (_hint(3, 256, 256), "q256x256"), (_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))
@@ -742,6 +790,18 @@ def all_checks(dev="cuda"):
                 add(f"ring_geglu_1536x640_{tag}", lambda dt=dt, hint=hint: check_geglu(1536, 640, dt, dev, tile_hint=hint))
                 add(f"ring_geglu_ragged_200x64_{tag}", lambda dt=dt, hint=hint: check_geglu(200, 64, dt, dev, tile_hint=hint))
         add("linear_ragged_200x328x192", lambda dt=dt: check_linear(200, 328, 192, dt, dev, rowbias=True))
+        # the hand-scheduled 256x192 tile (plain Linear only: no conv gather)
+        h192 = _hint(5, 256, 192)
+        add("h192_linear_768x640x640", lambda dt=dt: check_linear(768, 640, 640, dt, dev, tile_hint=h192))
+        add("h192_linear_ragged_1000x328x192", lambda dt=dt: check_linear(1000, 328, 192, dt, dev, rowbias=True, tile_hint=h192))
+        add("h192_linear_K64", lambda dt=dt: check_linear(300, 192, 64, dt, dev, tile_hint=h192))
+        add("h192_linear_K128", lambda dt=dt: check_linear(2500, 136, 128, dt, dev, tile_hint=h192))
+        add("h192_linear_3072x1280x1280", lambda dt=dt: check_linear(3072, 1280, 1280, dt, dev, tile_hint=h192))
+        add("h192_vt_B2_N768_C640", lambda dt=dt: check_vt(2, 768, 640, dt, dev, tile_hint=h192))
+        add("h192_vt_B4_N768_C1280", lambda dt=dt: check_vt(4, 768, 1280, dt, dev, tile_hint=h192))
+        add("h192_geglu_1536x640", lambda dt=dt: check_geglu(1536, 640, dt, dev, tile_hint=h192))
+        add("h192_geglu_ragged_200x64", lambda dt=dt: check_geglu(200, 64, dt, dev, tile_hint=h192))
+        add("h192_stream_f32_768x640x640", lambda dt=dt: check_stream_f32(768, 640, 640, dt, dev, tile_hint=h192))
         # 8-byte epilogue: forced (bit 15 of the hint) and by shape (N % 8 != 0)
         add("linear_768x640x640_narrow", lambda dt=dt: check_linear(768, 640, 640, dt, dev, rowbias=True, tile_hint=_hint(1, 128, 64) | 0x8000))
         add("linear_N324_narrow", lambda dt=dt: check_linear(500, 324, 128, dt, dev, rowbias=False))
@@ -832,6 +892,11 @@ def all_checks(dev="cuda"):
         add("attn_self_cfg4_N6144_h10", lambda dt=dt: check_attn_self(2, 10, 6144, dt, dev, n_garm=6144, b0=1))
         add("attn_self_cfg4_N1536_h20", lambda dt=dt: check_attn_self(2, 20, 1536, dt, dev, n_garm=1536, b0=1))
         add("attn_cross_77_16_N768", lambda dt=dt: check_attn_cross(4, 4, 768, dt, dev))
+        for hint, tag in ((0, "auto"), (_hint(1, 128, 64), "128x64"), (_hint(1, 128, 128), "128x128"), (_hint(1, 128, 256), "128x256")):
+            add(f"xattn_fused_B4_h20_N768_{tag}", lambda dt=dt, hint=hint: check_xattn_fused(4, 20, 768, 1280, dt, dev, tile_hint=hint))
+            add(f"xattn_fused_text_only_B2_h4_N96_{tag}", lambda dt=dt, hint=hint: check_xattn_fused(2, 4, 96, 256, dt, dev, n_ip=0, tile_hint=hint))
+        add("xattn_fused_B2_h10_N3072_ipscale0.5", lambda dt=dt: check_xattn_fused(2, 10, 3072, 640, dt, dev, ip_scale=0.5))
+        add("xattn_fused_ragged_keys_33_5", lambda dt=dt: check_xattn_fused(3, 2, 160, 128, dt, dev, n_text=33, n_ip=5))
         add("attn_cross_scale0.5_N200", lambda dt=dt: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5))
         for hint, tag in ((0, "auto"),) + tuple(RING_TILES):
             add(f"stream_f32_768x640x640_{tag}", lambda dt=dt, hint=hint: check_stream_f32(768, 640, 640, dt, dev, tile_hint=hint))
@@ -871,6 +936,10 @@ def all_checks(dev="cuda"):
     P("gn_precise_512_silu", lambda: check_gn_precise(2, 768, 512, dev), 2e-5)
     P("gn_precise_128_nosilu", lambda: check_gn_precise(1, 4096, 128, dev, silu=False), 2e-5)
     P("softmax_split_64x3072", lambda: check_softmax_split(64, 3072, dev), 2e-5)
+    P("softmax_split_padded_keys_825_of_832", lambda: check_softmax_split(37, 832, dev, n_valid=825), 2e-5)
+    for dt in (torch.float16, torch.bfloat16):
+        out.append((f"softmax_rows_64x3072[{dt}]", lambda dt=dt: check_softmax_rows(64, 3072, dt, dev), TOL[dt]))
+        out.append((f"softmax_rows_padded_keys_825_of_832[{dt}]", lambda dt=dt: check_softmax_rows(37, 832, dt, dev, n_valid=825), TOL[dt]))
     P("plin_768x512x512_3term", lambda: check_plin(768, 512, 512, dev), 2e-5)
     P("plin_768x512x512_exact_weights_2term", lambda: check_plin(768, 512, 512, dev, exact_w=True), 2e-5)
     P("plin_ragged_1000x64x128", lambda: check_plin(1000, 64, 128, dev, res=False), 2e-5)

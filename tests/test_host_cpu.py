@@ -127,7 +127,8 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
     t = json.load(open(ops.TUNE_PATH))
     gemm_ok = {0: {(128, 128), (128, 64), (64, 64)},
                1: {(256, 256), (128, 256), (128, 128), (128, 64), (64, 64)},
-               2: {(256, 256), (128, 256), (128, 64), (64, 64)}}
+               2: {(256, 256), (128, 256), (128, 64), (64, 64)},
+               5: {(256, 256), (256, 257), (256, 192)}}           # hand-scheduled Linear loop: 256x256 placement forms 0 / 1 (low nibble of BM), 256x192
     assert t["gemm"] and t["attn"]
     for key, h in t["gemm"].items():
         f = [int(x) for x in key.split(",")]
@@ -136,6 +137,10 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
         assert (bn, bm) in gemm_ok.get(variant, ()), (key, h)
         if f[8] == 1:
             assert bn >= 128, (key, "GEGLU needs 64-row wave tiles")
+        if f[8] == 4:
+            assert bn == 128 and variant in (1, 2), (key, "fused cross-attention: waves own 64 columns")
+        if variant == 5:
+            assert f[4] == 1 and f[6] == 1 and f[7] == 0, (key, "variant 5 is a plain-Linear tile")
     for key, v in t["attn"].items():
         assert len(key.split(",")) == 9
         flags, kernel, st, nw = (v >> 24) & 0xf, (v >> 16) & 0xff, (v >> 8) & 0xff, v & 0xff

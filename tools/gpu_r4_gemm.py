@@ -19,8 +19,8 @@ def hint(v, bn, bm):
     return (v << 28) | (bn << 16) | bm
 
 
-VARIANTS = [("r256x256", hint(1, 256, 256)), ("r128x256", hint(1, 128, 256)), ("h5f0", hint(5, 256, 256)), ("h5f1", hint(5, 256, 257)),
-            ("h5f2", hint(5, 256, 258)), ("h5f3", hint(5, 256, 259)), ("h5f4", hint(5, 256, 260))]
+VARIANTS = [("r256x256", hint(1, 256, 256)), ("r128x256", hint(1, 128, 256)), ("p128x64", hint(2, 128, 64)), ("h256f0", hint(5, 256, 256)),
+            ("h256f1", hint(5, 256, 257)), ("h192", hint(5, 256, 192))]
 
 
 def main():
@@ -63,7 +63,7 @@ def main():
 
     def qkv(h):                                                  # fused QKV of a TryonNet level-2 block: q | k plain, v transposed in key order
         ops.linear(x2, w5, out=qk_o, vt=vt_o, vt_n0=2560, vt_tokens=768, colscale_n=1280, colscale=ops.QSCALE, tile_hint=h)
-        return torch.cat([qk_o.reshape(-1), vt_o.reshape(-1)])
+        return vt_o                                              # (no torch.cat here: the first version of this probe timed a 31 MB copy with it)
     cases.append(("qkv 3072x3840x1280 with V^T (TryonNet L2)", 2.0 * 3072 * 3840 * 1280, qkv, lambda: torch.matmul(x2, w5.t())))
     x3, w6, r6 = r(9216, 1280), r(1280, 1280, scale=0.03), r(9216, 1280)
     cases.append(("proj 9216x1280x1280 + res", 2.0 * 9216 * 1280 * 1280, lambda h: ops.linear(x3, w6, res=r6, tile_hint=h), lambda: torch.matmul(x3, w6.t())))
