@@ -45,6 +45,10 @@ def check_probe_mfma(dtype, dev):
     return relerr(got, ref)
 
 
+def _hint(variant, bn, bm):
+    return (variant << 28) | (bn << 16) | bm
+
+
 # ------------------------------------------------------------------------------------------------ GEMM / conv
 def check_linear(M, N, K, dtype, dev, bias=True, res=True, rowbias=False, tile_hint=0, seed=0):
     from idm_vton_amd import ops
@@ -65,6 +69,31 @@ def check_linear(M, N, K, dtype, dev, bias=True, res=True, rowbias=False, tile_h
         ref = ref + rs.float()
     out = ops.linear(x, w, bias=b, res=rs, tile_hint=tile_hint, **kw)
     return relerr(out, ref)
+
+
+def check_splitk(M, N, K, dtype, dev, reps=4, seed=0, **kw):
+    """tile_hint variant 6 (128x256 tile, K halved over two workgroups that meet inside the launch): against fp32, bit-equal to itself over
+    repeated launches on one workspace (the sum of the two halves does not depend on which arrives first), counters back to zero."""
+    from idm_vton_amd import ops
+    keep = ops.SPLITK
+    ops.SPLITK = ws = ops.SplitKWorkspace(dev)
+    try:
+        h = _hint(6, 128, 256)
+        errs, outs = [], []
+        for r in range(reps):
+            errs.append(check_linear(M, N, K, dtype, dev, tile_hint=h, seed=seed, **kw))
+        x = _r(M, K, dtype=dtype, dev=dev, seed=seed + 7)
+        w = _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 8)
+        load = [_r(4096, 4096, dtype=dtype, dev=dev, seed=seed + 9 + i) for i in range(2)]
+        for r in range(reps):
+            (load[0] @ load[1]).sum()                                      # uneven background load on the chip between repetitions
+            outs.append(ops.linear(x, w, tile_hint=h).clone())
+        torch.cuda.synchronize()
+        same = all(torch.equal(outs[0], o) for o in outs[1:])
+        zero = int(ws.counter.abs().sum().item()) == 0
+        return max(errs) if (same and zero) else float("inf")
+    finally:
+        ops.SPLITK = keep
 
 
 def check_geglu(M, C, dtype, dev, seed=0, tile_hint=0):
@@ -746,10 +775,6 @@ def check_elementwise(B, h, w, dtype, dev, seed=0):
     return max(e1, e2, e3, e4)
 
 
-def _hint(variant, bn, bm):
-    return (variant << 28) | (bn << 16) | bm
-
-
 RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
               (_hint(3, 256, 256), "q256x256"), (_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
@@ -802,6 +827,12 @@ def all_checks(dev="cuda"):
         add("h192_geglu_1536x640", lambda dt=dt: check_geglu(1536, 640, dt, dev, tile_hint=h192))
         add("h192_geglu_ragged_200x64", lambda dt=dt: check_geglu(200, 64, dt, dev, tile_hint=h192))
         add("h192_stream_f32_768x640x640", lambda dt=dt: check_stream_f32(768, 640, 640, dt, dev, tile_hint=h192))
+        # 2-way split-K of the 128x256 tile, in-launch hand-off
+        add("splitk_3072x1280x5120", lambda dt=dt: check_splitk(3072, 1280, 5120, dt, dev))
+        add("splitk_3072x1280x1280", lambda dt=dt: check_splitk(3072, 1280, 1280, dt, dev))
+        add("splitk_ragged_1000x328x256_rowbias", lambda dt=dt: check_splitk(1000, 328, 256, dt, dev, rowbias=True))
+        add("splitk_K128", lambda dt=dt: check_splitk(520, 264, 128, dt, dev))
+        add("splitk_12288x640x2560_reps8", lambda dt=dt: check_splitk(12288, 640, 2560, dt, dev, reps=8))
         # 8-byte epilogue: forced (bit 15 of the hint) and by shape (N % 8 != 0)
         add("linear_768x640x640_narrow", lambda dt=dt: check_linear(768, 640, 640, dt, dev, rowbias=True, tile_hint=_hint(1, 128, 64) | 0x8000))
         add("linear_N324_narrow", lambda dt=dt: check_linear(500, 324, 128, dt, dev, rowbias=False))

@@ -24,7 +24,7 @@ def hint(variant, bn, bm):
 GEMM_CANDS = [("v0_128x128", hint(0, 128, 128)), ("v0_128x64", hint(0, 128, 64)), ("v0_64x64", hint(0, 64, 64)),
               ("p_256x256", hint(2, 256, 256)), ("p_128x256", hint(2, 128, 256)), ("p_128x64", hint(2, 128, 64)), ("p_64x64", hint(2, 64, 64)),
               ("r_256x256", hint(1, 256, 256)), ("r_128x256", hint(1, 128, 256)), ("r_128x128", hint(1, 128, 128)), ("r_128x64", hint(1, 128, 64)),
-              ("r_64x64", hint(1, 64, 64)), ("h_256x256", hint(5, 256, 257)), ("h_256x192", hint(5, 256, 192))]   # h = the hand-scheduled Linear loop (csrc/gemm_lin.hip)
+              ("r_64x64", hint(1, 64, 64)), ("h_256x256", hint(5, 256, 257)), ("h_256x192", hint(5, 256, 192)), ("k_128x256", hint(6, 128, 256))]   # k = 2-way split-K   # h = the hand-scheduled Linear loop (csrc/gemm_lin.hip)
 def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
     return ((thr << 2 | noprio << 1 | pair) << 24) | ((3 if deep else 2) << 16) | (stages << 8) | 8
 
@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--skip-ring", action="store_true", help="do not consider the LDS-ring GEMM variants")
     ap.add_argument("--skip-attn-variants", action="store_true", help="do not consider non-default attention variants")
+    ap.add_argument("--warm-weights", action="store_true", help="touch the weights back into the cache before every timed launch (the pre-round-4 regime)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tune_gfx950.json"))
     args = ap.parse_args()
     import bench
@@ -93,9 +94,12 @@ def main():
         for _ in range(args.iters):
             flush.zero_()
             if fn == "idmvton_gemm_conv":
-                # the state the real loop launches in: weights prefetched by the previous GEMM, activations just written by the
-                # previous kernel -- both cache resident (Infinity Cache), nothing L2-hot from an earlier repetition
-                touch(a.w, a.N * a.Ktot * 2)
+                # the state the real loop launches in: activations just written by the previous kernel (cache resident), WEIGHTS FROM HBM -- a
+                # denoising step streams ~11 GB of them, 40x the Infinity Cache, and the round-1 prefetch of the next launch's weights was
+                # removed in round 2 (no gain); until round 4 this loop still touched the weights back into the cache, which favoured
+                # tiles that re-read them (--warm-weights restores that regime for comparison)
+                if args.warm_weights:
+                    touch(a.w, a.N * a.Ktot * 2)
                 for i in range(a.nseg):
                     touch(a.seg[i].ptr, a.seg[i].bytes)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
