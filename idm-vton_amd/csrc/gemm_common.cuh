@@ -21,7 +21,6 @@ struct GemmParams {
     float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
     float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
     const float* ln_rowstats; const float* ln_colvec;    // consumer: LayerNorm folded into this GEMM (ln_rowstats = a producer's rs_final)
-    float* sk_ws; uint32_t* sk_counter; int sk_tiles;    // split-K (tile_hint variant 6): fp32 slabs [tiles][128 x 256], {ticket, flag} per tile
     XAttnParams xa;                                      // mode IDMVTON_EPI_XATTN: cross-attention applied to the accumulators (xattn.cuh)
 };
 

@@ -33,10 +33,8 @@
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
-// SK: this workgroup computes ONE HALF of the K range of its tile (split = 0 | 1) and the two halves meet inside the launch (see the hand-off
-// behind the main loop); `tile` = the tile's linear index (its slab / counters in the split-K workspace).
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR, bool XA = false, bool SK = false>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0, const int split = 0, const int tile = 0) {
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR, bool XA = false>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int NW = WN * WM;
@@ -65,8 +63,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     int x_pix[XI], x_oy[XI], x_ox[XI], x_c8[XI];
     uint32_t x_off[XI];                                  // LIN only
     const int HoWo = p.Ho * p.Wo;
-    const int kt0 = SK ? split * (p.Ktot >> 7) : 0;     // split-K: first 64-deep k-tile of this half
-    auto kbyte = [&](int t) -> uint32_t { return (uint32_t)(t + kt0) * 128u; };
+    auto kbyte = [&](int t) -> uint32_t { return (uint32_t)t * 128u; };
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int R = (wave * XI + i) * 8 + lrow;
@@ -232,7 +229,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         xa_h = (n0 + wn * SN) >> 6;
         xattn_load_k<T>(p.xa, xa_b, xa_h, lane, xkf);
     }
-    const int nt = SK ? p.Ktot >> 7 : p.Ktot >> 6;
+    const int nt = p.Ktot >> 6;
     if constexpr (!V1) {
         issue(0, 0);
         for (int t = 0; t < nt; ++t) {
@@ -259,57 +256,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
         }
     }
 
-    if constexpr (SK) {
-        // Two halves of K, two workgroups, ONE result: whoever takes the first ticket publishes its accumulators and leaves; the other waits
-        // for them, adds them to its own and runs the epilogue.  a + b is commutative in fp32, so the sum does not depend on who arrived
-        // first: bit-reproducible.  Transport (guide G16, recipe R1): 16-byte write-through (sc1) stores -> every wave drains its stores ->
-        // barrier -> one relaxed agent-scope flag store; the reader polls the flag relaxed, fences acquire once, then reads with sc1 loads.
-        // The first arriver only depends on itself, so the second's wait always ends.  Counters are left zero for the next launch.
-        static_assert(LIN && !TR && !XA, "split-K: plain Linear tiles");
-        constexpr int NT = NW * 64;
-        __syncthreads();                                 // every wave is done with the LDS stages (smem[0..3] is reused as a mailbox)
-        unsigned* cnt = p.sk_counter + 2 * tile;
-        if (threadIdx.x == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const unsigned ticket = *(volatile unsigned*)smem;
-        const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(p.sk_ws + (size_t)tile * (BN * BM), (uint32_t)(BN * BM * 4));
-        // slab image: [wave][accumulator][register quad][lane] x 16 bytes -- every store / load instruction moves 1 KiB contiguous
-        const uint32_t sbase = (uint32_t)(((wave * NI * MI) * 4 * 64 + lane) * 16);
-        if (ticket == 0) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const u32x4 v = {__float_as_uint(acc[ni][mi][4 * q]), __float_as_uint(acc[ni][mi][4 * q + 1]),
-                                         __float_as_uint(acc[ni][mi][4 * q + 2]), __float_as_uint(acc[ni][mi][4 * q + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_s, sbase + (uint32_t)(((ni * MI + mi) * 4 + q) * 1024), 0, 16 /* sc1: write-through */);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (threadIdx.x == 0) {
-            while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_s, sbase + (uint32_t)(((ni * MI + mi) * 4 + q) * 1024), 0, 16 /* sc1 */);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ni][mi][4 * q + j] += __uint_as_float(v[j]);
-                }
-        (void)NT;
-    }
     const float* fin = nullptr;                          // LDS: (rstd, -rstd*mean) of this tile's rows, nullptr = no folded LayerNorm
     if (p.ln_rowstats) {                                 // block-uniform: LayerNorm of the activation operand folded into this GEMM
         __syncthreads();                                 // every wave is done with the last LDS stage
@@ -438,23 +384,6 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_xattn_kernel(const Gem
     gemm_body<T, BN, BM, WN, WM, ST, true, true, OCC == 1, false, true>(p, smem, tm * BM, tn * BN);
 }
 
-// 2-way split-K of the 128 x 256 ring tile (tile_hint variant 6): M = 3072 with N = 1280 gives 120 such tiles -- fewer than half the CUs; with
-// each tile's K range halved over two workgroups the launch has 240 work items of the better tile instead of 240 128x128 / 480 128x64 tiles.
-template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_splitk_kernel(const GemmParams p) {
-    constexpr int BN = 128, BM = 256, ST = 3;
-    __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
-    const int w2 = xcd_remap(blockIdx.x, 2 * p.tiles_m * p.tiles_n);    // both halves of a tile: neighbours in one XCD's chunk of the grid
-    const int wg = w2 >> 1, split = w2 & 1;
-    constexpr int GM = 1024 / BM;
-    const int width = GM * p.tiles_n;
-    const int grp = wg / width, rem = wg - grp * width;
-    const int first = grp * GM;
-    const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
-    const int tn = rem / gsz, tm = first + (rem - tn * gsz);
-    gemm_body<T, BN, BM, 2, 4, ST, true, true, false, false, false, true>(p, smem, tm * BM, tn * BN, split, wg);
-}
-
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
 static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
@@ -517,12 +446,6 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
             p.tiles_n = (p.N + 127) / 128; p.tiles_m = (p.M + 255) / 256;
             launch_cfg<T, 128, 256, 2, 4, 3, true, 2>(p, lin, st);
         }
-    } else if (variant == 6) {                           // 2-way split-K, 128x256 tile
-        if (!(bn == 128 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 6 is the 128x256 tile");
-        if (!lin || p.vt || p.ln_rowstats || p.rs_counter || (p.Ktot & 127) || !p.sk_ws || !p.sk_counter || p.tiles_n * p.tiles_m > p.sk_tiles)
-            return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: split-K needs a plain Linear with K %% 128 == 0, no V^T / folded LayerNorm, and a "
-                                     "workspace for %d tiles (splitk_ws / splitk_counter, splitk_tiles=%d)", p.tiles_n * p.tiles_m, p.sk_tiles);
-        hipLaunchKernelGGL((gemm_splitk_kernel<T>), dim3(2 * p.tiles_n * p.tiles_m), dim3(512), 0, st, p);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     CHECK_LAUNCH("gemm_conv");
     return IDMVTON_OK;
@@ -609,9 +532,6 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.rowstats_out = a->rowstats_out; p.rs_parts = a->N / 32;
     p.rs_final = a->rowstats_final; p.rs_counter = a->rowstats_counter; p.rs_eps = a->rowstats_eps;
     p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec;
-    p.sk_ws = a->splitk_ws; p.sk_counter = a->splitk_counter; p.sk_tiles = a->splitk_tiles;
-    if (a->splitk_ws || a->splitk_counter) CHECK_ARG(a->splitk_ws && a->splitk_counter && a->splitk_tiles > 0 && ((uintptr_t)a->splitk_ws & 15) == 0 &&
-                                                     ((uintptr_t)a->splitk_counter & 3) == 0, IDMVTON_E_ARG, "gemm_conv: splitk_ws, splitk_counter and splitk_tiles come together");
     if (a->rowstats_out || a->rowstats_final || a->rowstats_counter) {
         CHECK_ARG(a->rowstats_out && a->rowstats_final && a->rowstats_counter && a->rowstats_eps > 0.f, IDMVTON_E_ARG,
                   "gemm_conv: rowstats_out, rowstats_final, rowstats_counter and rowstats_eps > 0 come together");

@@ -38,7 +38,6 @@ class GemmConvArgs(C.Structure):
                 ("rows_per_group", i32), ("res", vp), ("ldr", i32), ("mode", i32), ("vt", vp), ("vt_n0", i32),
                 ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("io_flags", i32), ("rowstats_out", vp), ("rowstats_final", vp), ("rowstats_counter", vp), ("rowstats_eps", f32),
                 ("ln_rowstats", vp), ("ln_colvec", vp), ("xattn", C.POINTER(XAttn)),
-                ("splitk_ws", vp), ("splitk_counter", vp), ("splitk_tiles", i32),
                 ("colscale_n", i32), ("colscale", f32)]
 
 

@@ -156,10 +156,6 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
             raise ValueError(f"RowStats({rs.M}, {rs.C}) on a consumer of [{M}][{Ktot}]")
         a.ln_rowstats, a.ln_colvec = _ptr(rs.final), _ptr(colvec)
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
-    if SPLITK is not None:                                # the caller's split-K workspace travels with every launch; only tile_hint variant 6 uses it
-        a.splitk_ws, a.splitk_counter, a.splitk_tiles = _ptr(SPLITK.ws), _ptr(SPLITK.counter), SPLITK.tiles
-    elif (a.tile_hint >> 28) & 0xf == 6:
-        a.tile_hint = 0                                   # a table entry asks for split-K but nobody lent a workspace: the heuristic tile
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt, xa, xattn)))
     seen, xbytes = set(), 0                               # algorithmic bytes: every distinct operand tensor once
@@ -177,20 +173,6 @@ def xattn_q_weight(w):
     """attn2.to_q weight [heads*64][K] -> rows in the ACCUMULATOR ORDER the fused cross-attention epilogue contracts in: inside every group of
     16 output channels, bits 2 and 3 of the channel index swapped (the same involution as key_order_index)."""
     return w.index_select(0, key_order_index(w.shape[0], w.device)).contiguous()
-
-
-class SplitKWorkspace:
-    """Scratch of the in-launch 2-way split-K (include/idmvton_hip.h, splitk_*): one fp32 slab of a 128 x 256 tile and a {ticket, flag} pair
-    per tile -- zero here, left zero by every launch.  One object serves launches that run one after another on ONE stream; assign it to
-    ops.SPLITK around them (HipUNet.forward does: each UNet of the pipeline owns one, they run on different streams)."""
-
-    def __init__(self, device, tiles=256):
-        self.tiles = tiles
-        self.ws = torch.empty(tiles * 128 * 256, dtype=torch.float32, device=device)
-        self.counter = torch.zeros(tiles * 2, dtype=torch.int32, device=device)
-
-
-SPLITK = None
 
 
 class RowStats:

@@ -86,7 +86,6 @@ class HipUNet:
         self.cin_pad = _pad64(cfg.in_channels)
         self._prep()
         self._gn_stats = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=self.device)
-        self._splitk = ops.SplitKWorkspace(self.device)     # 2-way split-K hand-off scratch of THIS net's launches (one stream, in order)
         self._ctx = None
 
     # ------------------------------------------------------------------------------------------------ weight prep
@@ -386,7 +385,6 @@ class HipUNet:
         the concatenated self-attention input, attentionhacked_tryon.py:334-342) -> [(K [Bg*N][C], V^T [Bg][C][N])] * 70.
         It depends only on GarmentNet's output, so the engine runs it on the GarmentNet stream, one step ahead of TryonNet."""
         assert self.tryon and len(feats) == len(self.block_order)
-        ops.SPLITK = None                                    # runs on the GarmentNet stream beside this net's own forward: no shared scratch
         res = []
         for i, (blk, g) in enumerate(zip(self.block_order, feats)):
             Bg, N, C = g.shape
@@ -405,7 +403,6 @@ class HipUNet:
         ctx: encode_context(); garment_feats: list of [Bg][N][C] (Bg <= B; batches < B-Bg see all-zero features).
         Returns (noise NHWC [B][H*W][n_out] for TryonNet | None, exported features for GarmentNet)."""
         topo = self.topo
-        ops.SPLITK = self._splitk
         garment = dict(feats=garment_feats, kv=garment_kv, feats_buf=feats_buf, idx=0)
         feats = []
         stop = None if self.tryon else self.num_features()

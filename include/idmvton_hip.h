@@ -95,7 +95,7 @@ typedef struct {
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
                                     variant 1 with register-prefetched fragments on every tile; variant 3 = 256x256 as 4 waves of 128x128 (AGPR
                                     accumulators, one wave per SIMD); variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
-                                    of the BM field = placement form 0 | 1) and 256x192; variant 6 = 128x256 with 2-way split-K (splitk_*).  Bit 15
+                                    of the BM field = placement form 0 | 1) and 256x192.  Bit 15
                                     (0x8000) forces the 8-byte epilogue (measurement only; default: 16-byte accesses when every
                                     epilogue operand is 16-byte aligned with strides / N multiples of 8).
                                     Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */
@@ -130,12 +130,6 @@ typedef struct {
     float* rowstats_out; float* rowstats_final; uint32_t* rowstats_counter; float rowstats_eps;
     const float* ln_rowstats; const float* ln_colvec;
     const idmvton_xattn* xattn;  /* mode IDMVTON_EPI_XATTN only (host pointer, read during the call) */
-    /* tile_hint variant 6: 2-way split-K of the 128x256 tile for launches whose M x N gives too few tiles (M = 3072, N = 1280: 120).  Each tile's K
-       range is halved over two workgroups of the SAME launch; the first to finish publishes its fp32 accumulators into the tile's slab and leaves,
-       the second adds them to its own (a + b is commutative: the result does not depend on the order) and runs the epilogue.  splitk_ws: fp32
-       [splitk_tiles][128 * 256]; splitk_counter: uint32 [splitk_tiles][2], ZERO before the first launch (every launch leaves them zero); not shared
-       by launches that may run concurrently.  NULL = split-K not available to this launch (variant 6 is then an error). */
-    float* splitk_ws; uint32_t* splitk_counter; int32_t splitk_tiles;
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */

@@ -71,31 +71,6 @@ def check_linear(M, N, K, dtype, dev, bias=True, res=True, rowbias=False, tile_h
     return relerr(out, ref)
 
 
-def check_splitk(M, N, K, dtype, dev, reps=4, seed=0, **kw):
-    """tile_hint variant 6 (128x256 tile, K halved over two workgroups that meet inside the launch): against fp32, bit-equal to itself over
-    repeated launches on one workspace (the sum of the two halves does not depend on which arrives first), counters back to zero."""
-    from idm_vton_amd import ops
-    keep = ops.SPLITK
-    ops.SPLITK = ws = ops.SplitKWorkspace(dev)
-    try:
-        h = _hint(6, 128, 256)
-        errs, outs = [], []
-        for r in range(reps):
-            errs.append(check_linear(M, N, K, dtype, dev, tile_hint=h, seed=seed, **kw))
-        x = _r(M, K, dtype=dtype, dev=dev, seed=seed + 7)
-        w = _r(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 8)
-        load = [_r(4096, 4096, dtype=dtype, dev=dev, seed=seed + 9 + i) for i in range(2)]
-        for r in range(reps):
-            (load[0] @ load[1]).sum()                                      # uneven background load on the chip between repetitions
-            outs.append(ops.linear(x, w, tile_hint=h).clone())
-        torch.cuda.synchronize()
-        same = all(torch.equal(outs[0], o) for o in outs[1:])
-        zero = int(ws.counter.abs().sum().item()) == 0
-        return max(errs) if (same and zero) else float("inf")
-    finally:
-        ops.SPLITK = keep
-
-
 def check_geglu(M, C, dtype, dev, seed=0, tile_hint=0):
     """GEGLU(x) = h * gelu(gate), [h | gate] = x W^T + b  (weights interleaved in 64-row blocks for the kernel)."""
     from idm_vton_amd import ops
@@ -827,12 +802,6 @@ def all_checks(dev="cuda"):
         add("h192_geglu_1536x640", lambda dt=dt: check_geglu(1536, 640, dt, dev, tile_hint=h192))
         add("h192_geglu_ragged_200x64", lambda dt=dt: check_geglu(200, 64, dt, dev, tile_hint=h192))
         add("h192_stream_f32_768x640x640", lambda dt=dt: check_stream_f32(768, 640, 640, dt, dev, tile_hint=h192))
-        # 2-way split-K of the 128x256 tile, in-launch hand-off
-        add("splitk_3072x1280x5120", lambda dt=dt: check_splitk(3072, 1280, 5120, dt, dev))
-        add("splitk_3072x1280x1280", lambda dt=dt: check_splitk(3072, 1280, 1280, dt, dev))
-        add("splitk_ragged_1000x328x256_rowbias", lambda dt=dt: check_splitk(1000, 328, 256, dt, dev, rowbias=True))
-        add("splitk_K128", lambda dt=dt: check_splitk(520, 264, 128, dt, dev))
-        add("splitk_12288x640x2560_reps8", lambda dt=dt: check_splitk(12288, 640, 2560, dt, dev, reps=8))
         # 8-byte epilogue: forced (bit 15 of the hint) and by shape (N % 8 != 0)
         add("linear_768x640x640_narrow", lambda dt=dt: check_linear(768, 640, 640, dt, dev, rowbias=True, tile_hint=_hint(1, 128, 64) | 0x8000))
         add("linear_N324_narrow", lambda dt=dt: check_linear(500, 324, 128, dt, dev, rowbias=False))

@@ -128,8 +128,7 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
     gemm_ok = {0: {(128, 128), (128, 64), (64, 64)},
                1: {(256, 256), (128, 256), (128, 128), (128, 64), (64, 64)},
                2: {(256, 256), (128, 256), (128, 64), (64, 64)},
-               5: {(256, 256), (256, 257), (256, 192)},
-               6: {(128, 256)}}                                   # 2-way split-K (in-launch hand-off)           # hand-scheduled Linear loop: 256x256 placement forms 0 / 1 (low nibble of BM), 256x192
+               5: {(256, 256), (256, 257), (256, 192)}}           # hand-scheduled Linear loop: 256x256 placement forms 0 / 1 (low nibble of BM), 256x192
     assert t["gemm"] and t["attn"]
     for key, h in t["gemm"].items():
         f = [int(x) for x in key.split(",")]
@@ -140,10 +139,8 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
             assert bn >= 128, (key, "GEGLU needs 64-row wave tiles")
         if f[8] == 4:
             assert bn == 128 and variant in (1, 2), (key, "fused cross-attention: waves own 64 columns")
-        if variant in (5, 6):
-            assert f[4] == 1 and f[6] == 1 and f[7] == 0, (key, "variants 5 / 6 are plain-Linear tiles")
-        if variant == 6:
-            assert f[3] % 128 == 0 and f[9] == 0, (key, "split-K: K % 128 == 0, no V^T part")
+        # variant 5 on a launch that is not a plain Linear (e.g. the split-precision P.V product: 2 K-segments) is legal: launch_gemm runs it on the
+        # compiler-scheduled tile of the same / the nearest shape (csrc/gemm_conv.hip), which is what the tuner then measured
     for key, v in t["attn"].items():
         assert len(key.split(",")) == 9
         flags, kernel, st, nw = (v >> 24) & 0xf, (v >> 16) & 0xff, (v >> 8) & 0xff, v & 0xff

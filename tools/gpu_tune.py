@@ -24,7 +24,7 @@ def hint(variant, bn, bm):
 GEMM_CANDS = [("v0_128x128", hint(0, 128, 128)), ("v0_128x64", hint(0, 128, 64)), ("v0_64x64", hint(0, 64, 64)),
               ("p_256x256", hint(2, 256, 256)), ("p_128x256", hint(2, 128, 256)), ("p_128x64", hint(2, 128, 64)), ("p_64x64", hint(2, 64, 64)),
               ("r_256x256", hint(1, 256, 256)), ("r_128x256", hint(1, 128, 256)), ("r_128x128", hint(1, 128, 128)), ("r_128x64", hint(1, 128, 64)),
-              ("r_64x64", hint(1, 64, 64)), ("h_256x256", hint(5, 256, 257)), ("h_256x192", hint(5, 256, 192)), ("k_128x256", hint(6, 128, 256))]   # k = 2-way split-K   # h = the hand-scheduled Linear loop (csrc/gemm_lin.hip)
+              ("r_64x64", hint(1, 64, 64)), ("h_256x256", hint(5, 256, 257)), ("h_256x192", hint(5, 256, 192))]   # h = the hand-scheduled Linear loop (csrc/gemm_lin.hip)
 def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
     return ((thr << 2 | noprio << 1 | pair) << 24) | ((3 if deep else 2) << 16) | (stages << 8) | 8
 
