@@ -18,7 +18,7 @@ cd /tmp
 for mode in default serial; do
   extra=""; [ $mode = serial ] && extra="--no-overlap"
   rm -rf $O/prof_$mode
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$mode -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline $extra > $O/${TAG}_bench_prof_$mode.json 2> $O/${TAG}_prof_$mode.err; echo "prof $mode rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$mode -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fp16-leg $extra > $O/${TAG}_bench_prof_$mode.json 2> $O/${TAG}_prof_$mode.err; echo "prof $mode rc=$?"
   db=$(find $O/prof_$mode -name "*.db" | head -1)
   if [ -n "$db" ]; then
     python $R/tools/rocpd_summary.py $db > $O/${TAG}_prof_${mode}_kernel_stats.txt

@@ -7,7 +7,7 @@ LABEL=${1:-"unlabelled"}
 export TMPDIR=/tmp
 cd /tmp
 for cnt in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $cnt -d $O/pmc_traffic_$cnt -o bench -- python $R/bench.py --steps 1 --warmup 0 --denoise-steps 6 --no-ramp --no-graph --no-overlap --no-cpu-baseline --no-roofline > $O/pmc_traffic_$cnt.json 2> $O/pmc_traffic_$cnt.err; echo "pmc $cnt rc=$?"
+  timeout 900 rocprofv3 --pmc $cnt -d $O/pmc_traffic_$cnt -o bench -- python $R/bench.py --steps 1 --warmup 0 --denoise-steps 6 --no-ramp --no-graph --no-overlap --no-cpu-baseline --no-roofline --no-fp16-leg > $O/pmc_traffic_$cnt.json 2> $O/pmc_traffic_$cnt.err; echo "pmc $cnt rc=$?"
 done
 cd $R
 python tools/pmc_summary.py $O/pmc_traffic_FETCH_SIZE $O/pmc_traffic_WRITE_SIZE --label "$LABEL" > $O/pmc_traffic.json && python - <<'PY'
