@@ -43,12 +43,6 @@ __device__ __forceinline__ i32x8 load32(const uint8_t* p) {
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
     return r;
 }
-__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
-// four floats -> four e4m3 bytes (byte i = value i)
-__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
-    int x = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, x, true);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_f8_kernel(const AttnF8Params p) {

@@ -130,3 +130,11 @@ int idmvton_set_error(int code, const char* fmt, ...);
 #define CHECK_ARG(cond, code, ...) do { if (!(cond)) return idmvton_set_error(code, __VA_ARGS__); } while (0)
 #define CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
     return idmvton_set_error(IDMVTON_E_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---- e4m3 (OCP fp8) packing, shared by attention_f8.hip and the GEMM epilogue's IDMVTON_IO_OUT_F8 form ----
+__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+// four floats -> four e4m3 bytes (byte i = value i)
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+    int x = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, x, true);
+}

@@ -18,6 +18,7 @@ struct GemmParams {
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
     int bias32;                                          // bias holds fp32 (plain 16-byte epilogue only): the split-precision VAE path
+    int out8; float o8_scale, vt8_scale;                 // IDMVTON_IO_OUT_F8: out / vt are e4m3 bytes (plain 16-byte epilogue; vt in attention_f8.hip's slot order)
     float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
     float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
     const float* ln_rowstats; const float* ln_colvec;    // consumer: LayerNorm folded into this GEMM (ln_rowstats = a producer's rs_final)
@@ -67,6 +68,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const int u = lane >> 5, l31 = lane & 31;
     const T* bias = (const T*)p.bias;
     if constexpr (TR) {
+        if (p.out8) {
+            // e4m3 V^T in the fp8 attention kernel's slot order: position 64t + 32u + 16kb + 4g + j <-> key 64t + 32kb + 8g + 4u + j.  The
+            // lane's 16 accumulator registers 4g + j ARE rows 8g + 4u + j of this 32-row tile (kb = bit 5 of its first row), i.e. 16
+            // consecutive positions: one 16-byte store per 32x32 tile and lane.
+            uint8_t* vt = (uint8_t*)p.vt;
+            const int Cv = p.N - p.vt_n0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + wn * SN + ni * 32 + l31;
+                if (n >= p.N) continue;
+                const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = m0 + wm * SM + mi * 32;                               // vt_tokens % 64 == 0: one batch element per 32 rows
+                    if (m >= p.M) continue;
+                    const int b = m / p.vt_tokens;
+                    const int tok = m - b * p.vt_tokens;
+                    int4 o;
+                    int w[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        w[g] = pack4_fp8(clamp448((acc[ni][mi][4 * g] + bv) * p.vt8_scale), clamp448((acc[ni][mi][4 * g + 1] + bv) * p.vt8_scale),
+                                         clamp448((acc[ni][mi][4 * g + 2] + bv) * p.vt8_scale), clamp448((acc[ni][mi][4 * g + 3] + bv) * p.vt8_scale));
+                    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+                    *(int4*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + (tok & ~63) + 32 * u + ((tok >> 1) & 16))) = o;
+                }
+            }
+            return;
+        }
         if (p.vt_perm) {
             // key order puts the tokens of accumulator groups g = 2gp, 2gp+1 (rows 8g + 4u + j) next to each other: 16 gp + 8u + 4(g&1) + j
             T* vt = (T*)p.vt;
@@ -201,6 +231,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     if (n < p.colscale_n) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] *= p.colscale;
+                    }
+                    if constexpr (NI * MI <= 8)            // (not in the 128x128-per-wave tile: the extra exit from this nest moves its accumulators to scratch)
+                    if (p.out8) {                          // block-uniform: e4m3 operands for idmvton_attn_f8, one byte per column
+                        int2 o;
+                        o.x = pack4_fp8(clamp448(v[0] * p.o8_scale), clamp448(v[1] * p.o8_scale), clamp448(v[2] * p.o8_scale), clamp448(v[3] * p.o8_scale));
+                        o.y = pack4_fp8(clamp448(v[4] * p.o8_scale), clamp448(v[5] * p.o8_scale), clamp448(v[6] * p.o8_scale), clamp448(v[7] * p.o8_scale));
+                        *(int2*)((uint8_t*)p.out + (size_t)m * p.ldo + n) = o;
+                        continue;
                     }
                     if (p.mode == IDMVTON_EPI_GELU) {
 #pragma unroll

@@ -436,8 +436,8 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unsupported v2 tile %dx%d", bn, bm);
     } else if (variant == 3) {                           // 256x256, 4 waves x (128x128): one wave per SIMD, accumulators in AGPRs, a third fewer
         if (!(bn == 256 && bm == 256)) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 3 is the 256x256 tile");   // LDS fragment reads
-        if (p.wide && !p.vt) launch_cfg<T, 256, 256, 2, 2, 2, true, 1>(p, lin, st);
-        else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue or a V^T part: the 8-wave tile
+        if (p.wide && !p.vt && !p.out8) launch_cfg<T, 256, 256, 2, 2, 2, true, 1>(p, lin, st);
+        else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue, a V^T part or e4m3 output: the 8-wave tile
     } else if (variant == 5) {                           // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
         if (!(bn == 256 && (bm == 256 || bm == 192))) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 5 is the 256x256 / 256x192 tile");
         if (lin && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, std::is_same<T, bf16_t>::value, bm, form, st);
@@ -548,6 +548,15 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.bias32 = (a->io_flags & IDMVTON_IO_BIAS_F32) ? 1 : 0;
     if (p.bias32) CHECK_ARG(a->bias && p.wide && !geglu && !a->vt && ((uintptr_t)a->bias & 15) == 0, IDMVTON_E_ARG,
                             "gemm_conv: IDMVTON_IO_BIAS_F32 needs a 16-byte aligned bias and the plain 16-byte epilogue (no GEGLU, no vt)");
+    CHECK_ARG((a->io_flags & ~15) == 0, IDMVTON_E_ARG, "gemm_conv: io_flags=%d", a->io_flags);
+    p.out8 = (a->io_flags & IDMVTON_IO_OUT_F8) ? 1 : 0;
+    p.o8_scale = a->f8_out_scale; p.vt8_scale = a->f8_vt_scale;
+    if (p.out8) {
+        CHECK_ARG(a->io_flags == IDMVTON_IO_OUT_F8 && a->mode == IDMVTON_EPI_NONE && !a->res && !a->rowbias && !a->ln_rowstats && !a->rowstats_out && p.wide,
+                  IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_OUT_F8 needs the plain 16-byte epilogue (no activation / residual / rowbias / fp32 IO / LayerNorm fold)");
+        CHECK_ARG((!a->out || a->f8_out_scale > 0.f) && (!a->vt || (a->f8_vt_scale > 0.f && a->vt_tokens % 64 == 0 && ((uintptr_t)a->vt & 15) == 0)),
+                  IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_OUT_F8: scales > 0, vt_tokens %% 64 == 0 (got %d), 16-byte aligned vt", a->vt_tokens);
+    }
     if (p.res32 || p.out32) {
         CHECK_ARG((a->io_flags & ~7) == 0 && !geglu && !a->vt, IDMVTON_E_ARG, "gemm_conv: io_flags=%d (fp32 res / out: no GEGLU, no vt)", a->io_flags);
         CHECK_ARG(!p.res32 || a->res, IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_RES_F32 without res");

@@ -12,12 +12,12 @@ LIB_PATH = os.environ.get("IDMVTON_HIP_LIB") or os.path.join(_HERE, "libidmvton_
 F16, BF16, F32, F8E4M3 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU, EPI_XATTN = 0, 1, 2, 3, 4
 ATTN_SELF, ATTN_CROSS = 0, 1
-IO_RES_F32, IO_OUT_F32, IO_BIAS_F32 = 1, 2, 4
+IO_RES_F32, IO_OUT_F32, IO_BIAS_F32, IO_OUT_F8 = 1, 2, 4, 8
 GN_X_F32, GN_Y_SPLIT, GN_AFFINE_F32 = 1, 2, 4
 LAYOUT_SPLIT, LAYOUT_NHWC_F32 = 1, 2
 SPLIT_ACT, SPLIT_W3, SPLIT_W3T = 0, 1, 2
 MAX_SEG = 24
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, u32, f32, vp = C.c_int32, C.c_uint32, C.c_float, C.c_void_p
 
@@ -38,7 +38,7 @@ class GemmConvArgs(C.Structure):
                 ("rows_per_group", i32), ("res", vp), ("ldr", i32), ("mode", i32), ("vt", vp), ("vt_n0", i32),
                 ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("io_flags", i32), ("rowstats_out", vp), ("rowstats_final", vp), ("rowstats_counter", vp), ("rowstats_eps", f32),
                 ("ln_rowstats", vp), ("ln_colvec", vp), ("xattn", C.POINTER(XAttn)),
-                ("colscale_n", i32), ("colscale", f32)]
+                ("colscale_n", i32), ("colscale", f32), ("f8_out_scale", f32), ("f8_vt_scale", f32)]
 
 
 class AttnArgs(C.Structure):

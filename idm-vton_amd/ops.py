@@ -89,8 +89,10 @@ class SegSpec:
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, quick_gelu=False, vt=None,
               vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, rowstats_out=None, ln=None,
-              xattn=None):
+              xattn=None, f8=None):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
+    f8 = (out_scale, vt_scale): `out` ([M][n_out] uint8) and `vt` ([B][N - vt_n0][vt_tokens] uint8, fp8 slot order) are written as e4m3
+    operands of attention_f8 (IDMVTON_IO_OUT_F8): value * scale, saturating, one rounding from the fp32 accumulator.
     fp32 residual stream: a float32 `res` is read as fp32; out_f32=True (or a float32 `out`) writes fp32 (io_flags).
     LayerNorm folded into the GEMMs around it: rowstats_out = a RowStats on the PRODUCER of a hidden state (its tiles emit (sum, sum of
     squares) per 32-column group of the stored values, the last tile to finish a row tile folds them to (rstd, -rstd*mean) per row);
@@ -123,10 +125,15 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.M, a.Ho, a.Wo, a.Hi, a.Wi, a.stride, a.ups = M, Ho, Wo, Hi, Wi, stride, int(bool(ups))
     n_out = N // 2 if geglu else (vt_n0 if vt is not None else N)
     if out is None and n_out > 0:
-        out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else w.dtype, device=w.device)
-    a.io_flags = (ffi.IO_RES_F32 if res is not None and res.dtype == torch.float32 else 0) | \
-                 (ffi.IO_OUT_F32 if out is not None and out.dtype == torch.float32 else 0) | \
-                 (ffi.IO_BIAS_F32 if bias is not None and bias.dtype == torch.float32 else 0)
+        out = torch.empty((M, n_out), dtype=torch.uint8 if f8 is not None else (torch.float32 if out_f32 else w.dtype), device=w.device)
+    if f8 is not None:
+        if (out is not None and out.dtype != torch.uint8) or (vt is not None and vt.dtype != torch.uint8):
+            raise TypeError("gemm_conv(f8=...): out / vt must be uint8 (e4m3 bytes)")
+        a.f8_out_scale, a.f8_vt_scale = float(f8[0]), float(f8[1])
+    a.io_flags = ffi.IO_OUT_F8 if f8 is not None else (
+        (ffi.IO_RES_F32 if res is not None and res.dtype == torch.float32 else 0) |
+        (ffi.IO_OUT_F32 if out is not None and out.dtype == torch.float32 else 0) |
+        (ffi.IO_BIAS_F32 if bias is not None and bias.dtype == torch.float32 else 0))
     a.out = _ptr(out)
     a.ldo = (ldo if ldo is not None else (out.stride(-2) if out is not None else 0))
     a.bias = _ptr(bias)

@@ -178,11 +178,11 @@ class TryonEngine:
         if like is None and key not in self._set_shapes:
             _, feats = self.unet_encoder.forward(st["cloth_k"], st["temb_gk"][0], st["ctx_gk"], k * B, h, w)
             kv = self.unet.project_garment_kv(feats)
-            self._set_shapes[key] = ([tuple(f.shape) for f in feats], [(tuple(kk.shape), tuple(vv.shape)) for kk, vv in kv])
+            self._set_shapes[key] = ([tuple(f.shape) for f in feats], [(tuple(kk.shape), tuple(vv.shape), kk.dtype) for kk, vv in kv])
         elif like is None:
             fs, ks = self._set_shapes[key]
             feats = [torch.empty(sh, dtype=self.dtype, device=self.device) for sh in fs]
-            kv = [(torch.empty(a, dtype=self.dtype, device=self.device), torch.empty(b, dtype=self.dtype, device=self.device)) for a, b in ks]
+            kv = [(torch.empty(a, dtype=d, device=self.device), torch.empty(b, dtype=d, device=self.device)) for a, b, d in ks]   # d: uint8 = e4m3 (attn_fp8)
         else:
             feats = [torch.empty_like(f) for f in like["feats"]]
             kv = [(torch.empty_like(kk), torch.empty_like(vv)) for kk, vv in like["kv"]]

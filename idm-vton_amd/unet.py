@@ -76,6 +76,7 @@ class HipUNet:
         # (csrc/xattn.cuh).  Same arithmetic as the two launches (q rounded once to the storage type, fp32 logits and softmax, P rounded for P.V)
         self.fuse_xattn = bool(fuse_xattn) and os.environ.get("IDMVTON_FUSE_XATTN", "1") != "0"
         self.f8_exp = (2, 2, 2)
+        self.f8_fused = os.environ.get("IDMVTON_F8_FUSED", "1") != "0"     # 0: project in 16 bits, then idmvton_quant_f8 (the round-3 form; A/B only)
         self.topo = unet_topology(cfg)
         sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items() if not k.startswith("encoder_hid_proj.")}
         self.sd = sd
@@ -256,8 +257,14 @@ class HipUNet:
         if not self.tryon:                                       # exported norm1 output (garmnet :321-322)
             fb = garment.get("feats_buf") if garment else None
             feat = fb[len(feats_out)][:B].view(M, C) if fb is not None else torch.empty(M, C, dtype=dt, device=dev)
-        qk = torch.empty(M, 2 * C, dtype=dt, device=dev)
-        vt = torch.empty(B, C, N, dtype=dt, device=dev)
+        # attn_fp8: the projections write the e4m3 operands themselves (IDMVTON_IO_OUT_F8: one rounding, no quant launches) when the token
+        # rows are whole 64-key tiles; other sizes project in 16 bits and quantise with idmvton_quant_f8
+        f8 = self._f8_fused(N) and not (fuse and self.tryon)
+        eq, ek, ev = self.f8_exp
+        f8kw = dict(f8=(2.0 ** ek, 2.0 ** ev)) if f8 else {}
+        qk = torch.empty(M, 2 * C, dtype=torch.uint8 if f8 else dt, device=dev)
+        vt = torch.empty(B, C, N, dtype=torch.uint8 if f8 else dt, device=dev)
+        qcs = ops.QSCALE * (2.0 ** (eq - ek) if f8 else 1.0)     # q columns: softmax scale (and 2^eq over the 2^ek every `out` column gets)
         # q columns leave the GEMM multiplied by softmax_scale * log2(e) (fp32, before the one rounding to the storage dtype)
         if fuse and self.tryon:                                  # norm1 folded into the QKV projection
             ops.linear(hs, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE, ln=(rs, blk["qkv_cv"]))
@@ -267,7 +274,7 @@ class HipUNet:
                 feats_out.append(feat.view(B, N, C))
                 if stop is not None and len(feats_out) >= stop:
                     return None                          # GarmentNet: everything after the last export is dead compute
-            ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE)
+            ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=qcs, **f8kw)
         segs = [dict(k=qk[:, C:], vt=vt, nk=nk, ldk=2 * C, ldvt=N, k_rows=N)]
         if self.tryon:
             if garment.get("kv") is not None:                   # K / V^T of the garment tokens projected ahead of time
@@ -280,22 +287,27 @@ class HipUNet:
                     gp = torch.zeros(Bg, N, C, dtype=dt, device=dev)
                     gp[:, :g.shape[1]] = g
                     g = gp
-                kg = torch.empty(Bg * N, C, dtype=dt, device=dev)
-                vtg = torch.empty(Bg, C, N, dtype=dt, device=dev)
-                ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
+                kg = torch.empty(Bg * N, C, dtype=torch.uint8 if f8 else dt, device=dev)
+                vtg = torch.empty(Bg, C, N, dtype=torch.uint8 if f8 else dt, device=dev)
+                ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N, **f8kw)
             garment["idx"] += 1
             segs.append(dict(k=kg, vt=vtg, nk=nk, ldk=C, ldvt=N, k_rows=N, b0=B - Bg))
         att = torch.empty(M, C, dtype=dt, device=dev)
         if self.attn_fp8:
-            eq, ek, ev = self.f8_exp
             segs8 = []
             for sg in segs:
                 Bs = sg["vt"].shape[0]
+                if sg["k"].dtype == torch.uint8:                                            # written as e4m3 by its projection
+                    segs8.append(dict(k8=sg["k"], vt8=sg["vt"], nk=nk, ldk=sg["ldk"], ldvt=N, k_rows=N, b0=sg.get("b0", 0)))
+                    continue
                 k8 = ops.quant_f8(sg["k"], 2.0 ** ek)                                   # [Bs*N][C] (row stride ldk)
                 vt8 = ops.quant_f8(sg["vt"].reshape(Bs * C, N), 2.0 ** ev, mode=1)      # 16-bit key order -> fp8 slot order
                 segs8.append(dict(k8=k8, vt8=vt8, nk=nk, ldk=C, ldvt=vt8.shape[1], k_rows=N, b0=sg.get("b0", 0)))
-            q8 = ops.quant_f8(qk[:, :C], 2.0 ** eq)
-            ops.attention_f8(q8, att, segs8, heads, qk_scale_exp=-(eq + ek), v_scale_exp=-ev, B=B, Nq=N, ldq=C, ldo=C)
+            if f8:
+                q8, ldq8 = qk, 2 * C
+            else:
+                q8, ldq8 = ops.quant_f8(qk[:, :C], 2.0 ** eq), C
+            ops.attention_f8(q8, att, segs8, heads, qk_scale_exp=-(eq + ek), v_scale_exp=-ev, B=B, Nq=N, ldq=ldq8, ldo=C)
         else:
             ops.attention(qk, att, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C, q_prescaled=True)
         f32 = hs.dtype == torch.float32                          # the fp32 residual stream (see __init__)
@@ -380,6 +392,9 @@ class HipUNet:
     def num_features(self):
         return sum(len(t["blocks"]) for t in self.tf.values())
 
+    def _f8_fused(self, N):
+        return self.attn_fp8 and self.f8_fused and N % 64 == 0
+
     def project_garment_kv(self, feats, out=None):
         """TryonNet only: attn1.to_k / to_v of every block applied to the matching GarmentNet feature (the garment half of
         the concatenated self-attention input, attentionhacked_tryon.py:334-342) -> [(K [Bg*N][C], V^T [Bg][C][N])] * 70.
@@ -388,12 +403,14 @@ class HipUNet:
         res = []
         for i, (blk, g) in enumerate(zip(self.block_order, feats)):
             Bg, N, C = g.shape
+            f8 = self._f8_fused(N)                               # e4m3 straight from the projection (see _block)
             if out is not None:
                 kg, vtg = out[i][0][:Bg * N], out[i][1][:Bg]     # the persistent set is sized for the largest block
             else:
-                kg = torch.empty(Bg * N, C, dtype=self.dtype, device=self.device)
-                vtg = torch.empty(Bg, C, N, dtype=self.dtype, device=self.device)
-            ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N)
+                kg = torch.empty(Bg * N, C, dtype=torch.uint8 if f8 else self.dtype, device=self.device)
+                vtg = torch.empty(Bg, C, N, dtype=torch.uint8 if f8 else self.dtype, device=self.device)
+            f8kw = dict(f8=(2.0 ** self.f8_exp[1], 2.0 ** self.f8_exp[2])) if f8 else {}
+            ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N, **f8kw)
             res.append((kg, vtg))
         return res
 

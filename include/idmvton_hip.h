@@ -79,7 +79,7 @@ typedef struct {
     int32_t nk[2];               /* <= 96 */
     int32_t tokens; float ip_scale;
 } idmvton_xattn;
-enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2, IDMVTON_IO_BIAS_F32 = 4 };
+enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2, IDMVTON_IO_BIAS_F32 = 4, IDMVTON_IO_OUT_F8 = 8 };
 typedef struct {
     int32_t dtype;               /* IDMVTON_F16 | IDMVTON_BF16 (X, W, out, bias, res, rowbias all this type; see io_flags) */
     const void* w; int32_t N; int32_t Ktot;
@@ -133,6 +133,13 @@ typedef struct {
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
                                     already scaled by softmax_scale * log2(e) (idmvton_attn_args.q_prescaled). */
+    float f8_out_scale, f8_vt_scale; /* io_flags & IDMVTON_IO_OUT_F8 (ABI 7): the projection that feeds idmvton_attn_f8 writes its operands itself -- `out`
+                                    (ldo in BYTES) receives e4m3(clamp(+-448, value * f8_out_scale)) after colscale, one byte per column, and `vt`
+                                    receives e4m3(clamp(value * f8_vt_scale)) as [B][N - vt_n0][vt_tokens] bytes in the fp8 kernel's SLOT ORDER (position
+                                    64t + 32u + 16kb + 4g + j holds key 64t + 32kb + 8g + 4u + j: exactly what idmvton_quant_f8 mode 1 produces from the
+                                    16-bit V^T; vt_perm is ignored).  Scales are powers of two (they ride on the MFMA's E8M0 operands).  Needs the plain
+                                    16-byte epilogue (no GEGLU / residual / fp32 IO / LayerNorm fold / rowstats), vt_tokens % 64 == 0, 16-byte aligned
+                                    pointers.  One rounding from the fp32 accumulator instead of two (16-bit, then e4m3), no idmvton_quant_f8 launches. */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);
 

@@ -277,6 +277,76 @@ def check_quant_f8(dtype, dev, seed=0):
     return 0.0 if ok else float("inf")
 
 
+def check_gemm_f8_out(dtype, dev, B=2, N=192, C=128, K=320, hint=0, seed=0, fused_attn=False):
+    """The QKV projection writing e4m3 operands itself (IDMVTON_IO_OUT_F8): q (softmax-scaled) | k into `out` bytes, V^T into the fp8
+    kernel's slot order -- against the fp32 product of the same 16-bit operands, quantised by torch.  One e4m3 rounding of the kernel's fp32
+    accumulator vs one of the reference's: they may land on neighbouring codes when the accumulators differ in their last bits, so the
+    comparison is in value: |got - ref*scale| <= half an e4m3 ulp of the larger (2^-4 relative, 2^-10 in the subnormal range) + the
+    accumulation-order slack.  fused_attn: also feed the bytes to idmvton_attn_f8 and return its error against the two-launch route
+    (16-bit projection -> idmvton_quant_f8 -> idmvton_attn_f8) on the same inputs: both are e4m3 roundings of the same values."""
+    from idm_vton_amd import ops
+    M = B * N
+    x = _r(M, K, dtype=dtype, dev=dev, scale=1.0, seed=seed)
+    w = _r(3 * C, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 1)
+    so, sv = 4.0, 2.0
+    qk8 = torch.empty(M, 2 * C, dtype=torch.uint8, device=dev)
+    vt8 = torch.empty(B, C, N, dtype=torch.uint8, device=dev)
+    ops.linear(x, w, out=qk8, vt=vt8, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE, f8=(so, sv), tile_hint=hint)
+    y = x.float() @ w.float().t()
+    ref_o = torch.cat([y[:, :C] * ops.QSCALE, y[:, C:2 * C]], 1) * so
+    got_o = qk8.view(torch.float8_e4m3fn).float()
+    pos = torch.arange(N, device=dev)
+    key = 64 * (pos // 64) + 32 * ((pos // 16) % 2) + 8 * ((pos // 4) % 4) + 4 * ((pos // 32) % 2) + pos % 4
+    ref_v = (y[:, 2 * C:].view(B, N, C).transpose(1, 2) * sv)[:, :, key]            # [B][C][position]
+    got_v = vt8.view(torch.float8_e4m3fn).float()
+    worst = 0.0
+    for got, ref in ((got_o, ref_o), (got_v, ref_v)):
+        ref = ref.clamp(-448.0, 448.0)
+        tol = ref.abs() * (2.0 ** -4 + 4e-3) + 2.0 ** -10 + 1e-3
+        worst = max(worst, float(((got - ref).abs() / tol).max()))
+    err = 0.0 if worst <= 1.0 else worst
+    if fused_attn and err == 0.0:
+        heads = C // 64
+        a1 = torch.empty(M, C, dtype=dtype, device=dev)
+        ops.attention_f8(qk8, a1, [dict(k8=qk8[:, C:], vt8=vt8, nk=N, ldk=2 * C, ldvt=N, k_rows=N)], heads, qk_scale_exp=-4, v_scale_exp=-1, B=B, Nq=N, ldq=2 * C, ldo=C)
+        qk16 = torch.empty(M, 2 * C, dtype=dtype, device=dev)
+        vt16 = torch.empty(B, C, N, dtype=dtype, device=dev)
+        ops.linear(x, w, out=qk16, vt=vt16, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE)
+        q8 = ops.quant_f8(qk16[:, :C], so)
+        k8 = ops.quant_f8(qk16[:, C:], so)
+        v8 = ops.quant_f8(vt16.view(B * C, N), sv, mode=1)
+        a2 = torch.empty(M, C, dtype=dtype, device=dev)
+        ops.attention_f8(q8, a2, [dict(k8=k8, vt8=v8, nk=N, ldk=C, ldvt=v8.shape[1], k_rows=N)], heads, qk_scale_exp=-4, v_scale_exp=-1, B=B, Nq=N, ldq=C, ldo=C)
+        return relerr(a1, a2)
+    return err
+
+
+def check_gemm_f8_kv(dtype, dev, Bg=3, N=128, C=128, K=192, seed=3):
+    """The garment K / V^T projection of the fp8 path (vt_n0 = C, no colscale) + the argument contract of IDMVTON_IO_OUT_F8."""
+    from idm_vton_amd import ops
+    g = _r(Bg * N, K, dtype=dtype, dev=dev, scale=1.0, seed=seed)
+    w = _r(2 * C, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=seed + 1)
+    k8 = torch.empty(Bg * N, C, dtype=torch.uint8, device=dev)
+    vt8 = torch.empty(Bg, C, N, dtype=torch.uint8, device=dev)
+    ops.linear(g, w, out=k8, vt=vt8, vt_n0=C, vt_tokens=N, f8=(4.0, 4.0))
+    y = g.float() @ w.float().t() * 4.0
+    pos = torch.arange(N, device=dev)
+    key = 64 * (pos // 64) + 32 * ((pos // 16) % 2) + 8 * ((pos // 4) % 4) + 4 * ((pos // 32) % 2) + pos % 4
+    worst = 0.0
+    for got, ref in ((k8.view(torch.float8_e4m3fn).float(), y[:, :C]), (vt8.view(torch.float8_e4m3fn).float(), y[:, C:].view(Bg, N, C).transpose(1, 2)[:, :, key])):
+        ref = ref.clamp(-448.0, 448.0)
+        worst = max(worst, float(((got - ref).abs() / (ref.abs() * (2.0 ** -4 + 4e-3) + 2.0 ** -10 + 1e-3)).max()))
+    bad = 0
+    for kw in (dict(vt_tokens=96), dict(res=torch.zeros(Bg * N, C, dtype=dtype, device=dev)), dict(gelu=True)):   # 96 % 64 != 0; residual; activation
+        try:
+            vt_tokens = kw.pop("vt_tokens", N)
+            ops.linear(g[:Bg * vt_tokens] if vt_tokens != N else g, w, out=k8, vt=vt8, vt_n0=C, vt_tokens=vt_tokens, f8=(4.0, 4.0), **kw)
+            bad += 1
+        except Exception:
+            pass
+    return 0.0 if worst <= 1.0 and bad == 0 else max(worst, float(bad))
+
+
 def check_attn_f8(B, heads, N, dtype, dev, n_garm=0, b0=0, seed=0, eq=2, ek=2, ev=2):
     """fp8 self-attention (idmvton_attn_f8) with the TryonNet attn1 semantics of check_attn_self.  Returns (error against fp32 SDPA on
     the UNQUANTISED operands, error against fp32 SDPA on the dequantised e4m3 operands): the second isolates the kernel's own
@@ -869,6 +939,15 @@ def all_checks(dev="cuda"):
             add(f"attn_f8_{nm}", lambda dt=dt, a=args: check_attn_f8(a[0], a[1], a[2], dt, dev, n_garm=a[3], b0=a[4])[0], 1.2e-1)
             add(f"attn_f8_kernel_only_{nm}", lambda dt=dt, a=args: check_attn_f8(a[0], a[1], a[2], dt, dev, n_garm=a[3], b0=a[4])[1], 3e-2)
         add("quant_f8", lambda dt=dt: check_quant_f8(dt, dev), 0.0)
+        # the projections of the fp8 path writing e4m3 themselves (IDMVTON_IO_OUT_F8), on every tile family the tuned table may select
+        for hn, hv in (("auto", 0), ("r128x128", _hint(1, 128, 128)), ("r128x256", _hint(1, 128, 256)), ("r256x256", _hint(1, 256, 256)),
+                       ("p128x64", _hint(2, 128, 64)), ("v0_128x128", _hint(0, 128, 128)), ("h256", _hint(5, 256, 256)), ("h256f1", _hint(5, 256, 257)),
+                       ("h192", _hint(5, 256, 192))):
+            add(f"gemm_f8_out_{hn}", lambda dt=dt, hv=hv: check_gemm_f8_out(dt, dev, B=2, N=192, C=256, K=320, hint=hv), 0.0)
+        add("gemm_f8_out_N768_C640", lambda dt=dt: check_gemm_f8_out(dt, dev, B=4, N=768, C=640, K=640), 0.0)
+        add("gemm_f8_out_bias_free_kv_only", lambda dt=dt: check_gemm_f8_kv(dt, dev), 0.0)
+        # the same bytes through idmvton_attn_f8 vs the two-launch route: both are e4m3 roundings of the same values (one vs two roundings)
+        add("gemm_f8_out_feeds_attn_f8", lambda dt=dt: check_gemm_f8_out(dt, dev, B=2, N=256, C=128, K=256, fused_attn=True), 6e-2)
         add("linear_colscale", lambda dt=dt: check_colscale(dt, dev))
         add("linear_quickgelu", lambda dt=dt: check_quickgelu(dt, dev))
         add("attn_small_text_causal_77_d64", lambda dt=dt: check_attn_small(2, 12, 77, 64, dt, dev, True))
