@@ -20,8 +20,10 @@
 //   ds_read of tile t was waited for before its first MFMA of step 3, i.e. before it reached the barrier.
 //
 // Geometries (8 waves = two per SIMD: one wave's DMA issue -- ~60 cycles per LDS-DMA instruction, twice an MFMA gap -- is covered by
-// its partner's MFMAs; the 4-wave 128x128-per-wave form has nobody to cover it and measured 887-913 TFLOP/s on the 3072x10240x1280
-// GEGLU against 989-1027 for the 8-wave forms, profiles/r04_gemm_probe_h4_vs_h5_v1.log -- removed):
+// its partner's MFMAs; the 4-wave 128x128-per-wave form measured 887-913 TFLOP/s on the 3072x10240x1280 GEGLU against 989-1027 for the
+// 8-wave forms, profiles/r04_gemm_probe_h4_vs_h5_v1.log, and the same geometry fed by plain buffer loads + ds_write_b128 instead of LDS-DMA
+// (fire-and-forget issue, a whole k-tile for the data to land) 855 against 1024, profiles/r04_gemm_probe_h4g_buffer_load_form.log: one wave
+// per SIMD is not held back by the DMA issue but by having nobody to cover ANY of its waits -- both removed, kept in history):
 //   256 x 256 : 2 (n) x 4 (m) waves of 128 x 64
 //   256 x 192 : 4 (n) x 2 (m) waves of  64 x 96   -- 3072 x 3840 (fused QKV) and 9216 x 1280 give 240 tiles of it (one per CU, 94 % of the
 //                                                    chip) where 256 x 256 gives 180 (70 %)
@@ -188,180 +190,6 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, c
     gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, nullptr);
 }
 
-// ---- 256 x 256 as 4 waves of 128 x 128 (one wave per SIMD, a third fewer fragment bytes out of LDS per MFMA than the 8-wave form) with the
-// operands moved HBM -> VGPR -> LDS by plain buffer loads + ds_write_b128 instead of LDS-DMA: the DMA form of this geometry lost to the 8-wave
-// tile because one wave per SIMD has nobody to cover a DMA issue; a buffer load into registers is fire-and-forget, its ds_write rides in an
-// MFMA gap like a fragment read, and the data has a whole k-tile to land (loads of tile t+2 are issued during tile t, written to LDS
-// during tile t+1's first half, consumed in tile t+2).  Same LDS image as the DMA forms (lane-linear 16-byte pieces, XOR swizzle on the
-// global address and on the fragment read), two 64 KiB stages.  Per k-tile and wave: 64 MFMAs, 32 fragment reads, 16 ds_writes, 16 loads.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T, int WAIT_AT>
-__device__ __forceinline__ void gemm_lin4_body(const GemmParams& p, char* smem, const int m0, const int n0) {
-    typedef typename VT<T>::v8 v8;
-    constexpr int BN = 256, BM = 256, WM = 2, NW = 4, SN = 128, SM = 128, NI = 4, MI = 4, PW = 8;
-    constexpr int OPW = BN * 128, BUF = (BN + BM) * 128;
-    const int lane = threadIdx.x & 63;
-    const int wave = uniform(threadIdx.x >> 6);
-    const int wn = wave / WM, wm = wave % WM;
-    const int u = lane >> 5, l31 = lane & 31;
-
-    const int lrow = lane >> 3, lslot = lane & 7;
-    uint32_t w_off[PW], x_off[PW];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int R = (wave * PW + i) * 8 + lrow;
-        w_off[i] = ((uint32_t)(n0 + R) * (uint32_t)p.Ktot + (lslot ^ ((R >> 1) & 7)) * 8) * 2u;
-        const int m = m0 + R;
-        x_off[i] = m < p.M ? ((uint32_t)m * (uint32_t)p.seg[0].pitch + p.seg[0].coff + (lslot ^ ((R >> 1) & 7)) * 8) * 2u : OOB_SENTINEL;
-    }
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
-    char* const dW = smem + wave * (PW * 1024) + lane * 16;
-    char* const dX = smem + OPW + wave * (PW * 1024) + lane * 16;
-    u32x4 sw[PW], sx[PW];                                // staging registers: one k-tile of this wave's share (16 KiB per wave)
-    auto load_w = [&](uint32_t koff) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) sw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], koff, 0);
-    };
-    auto load_x = [&](uint32_t koff) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) sx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[i], koff, 0);
-    };
-    auto store_w = [&](int buf_off) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) *(u32x4*)(dW + buf_off + i * 1024) = sw[i];
-    };
-    auto store_x = [&](int buf_off) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) *(u32x4*)(dX + buf_off + i * 1024) = sx[i];
-    };
-
-    const int swz = (l31 >> 1) & 7;
-    int fa_off[4], fb_off[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int ch = ((2 * s + u) ^ swz) << 4;
-        fa_off[s] = (wn * SN + l31) * 128 + ch;
-        fb_off[s] = OPW + (wm * SM + l31) * 128 + ch;
-    }
-    v8 fa[2][NI], fb[2][MI];
-    f32x16 acc[NI][MI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-    auto read_all = [&](int set, int s, int buf_off) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fa[set][ni] = *(const v8*)(smem + buf_off + fa_off[s] + ni * 4096);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fb[set][mi] = *(const v8*)(smem + buf_off + fb_off[s] + mi * 4096);
-    };
-    auto mfma_range = [&](int set, int i0, int i1) {
-#pragma unroll
-        for (int idx = i0; idx < i1; ++idx) {
-            const int ni = idx / MI, mi = idx % MI;
-            acc[ni][mi] = VT<T>::mfma(fa[set][ni], fb[set][mi], acc[ni][mi]);
-        }
-    };
-    constexpr int NMF = NI * MI, NRD = NI + MI;          // 16 MFMAs, 8 fragment reads per k-step
-    // pin one k-step of 16 gaps: gap i = 1 MFMA, then (i < nrd) a fragment read, (i >= 16 - nwr_back) or (i < nwr_front) a ds_write,
-    // (i >= 16 - nld) a buffer load
-    auto pin = [&](int nrd, int nwr_front, int nwr_back, int nld) {
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (i < nwr_front || i >= NMF - nwr_back) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            if (i >= NMF - nld) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-    };
-
-    const int nt = p.Ktot >> 6;
-    // ---- prologue: tile 0 -> registers -> buffer 0; tile 1 -> registers; step-0 fragments of tile 0 ----
-    load_w(0u); load_x(0u);
-    store_w(0); store_x(0);
-    {
-        const uint32_t k1 = (uint32_t)(nt > 1 ? 1 : 0) * 128u;
-        load_w(k1); load_x(k1);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_all(0, 0, 0);
-
-    int cur = 0;
-    for (int t = 0; t + 1 < nt; ++t) {
-        const int nxt = cur ^ BUF;
-        const uint32_t k2 = (uint32_t)(t + 2 < nt ? t + 2 : nt - 1) * 128u;    // (the tile after the last is never used: re-read a valid one)
-        // ---- step 0: fragments of step 1; the weight half of tile t+1 goes to LDS ----
-        read_all(1, 1, cur);
-        store_w(nxt);
-        mfma_range(0, 0, NMF);
-        pin(NRD, 0, PW, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 1: fragments of step 2; the activation half of tile t+1 goes to LDS; weight loads of tile t+2 ----
-        read_all(0, 2, cur);
-        store_x(nxt);
-        load_w(k2);
-        mfma_range(1, 0, NMF);
-        pin(NRD, PW, 0, PW);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 2: fragments of step 3; activation loads of tile t+2 ----
-        read_all(1, 3, cur);
-        load_x(k2);
-        mfma_range(0, 0, NMF);
-        pin(NRD, 0, 0, PW);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- step 3: cross into tile t+1 ----
-        mfma_range(1, 0, WAIT_AT);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's ds_writes of tile t+1 (issued >= 2 k-steps ago) and its reads of tile t
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        read_all(0, 0, nxt);
-        mfma_range(1, WAIT_AT, NMF);
-#pragma unroll
-        for (int i = 0; i < NMF - WAIT_AT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    }
-    read_all(1, 1, cur);
-    mfma_range(0, 0, NMF);
-    pin(NRD, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_all(0, 2, cur);
-    mfma_range(1, 0, NMF);
-    pin(NRD, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_all(1, 3, cur);
-    mfma_range(0, 0, NMF);
-    pin(NRD, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_range(1, 0, NMF);
-
-    gemm_epilogue<T, NI, MI, SN, SM, false>(p, acc, m0, n0, wn, wm, lane, nullptr);
-}
-
-template <typename T, int WAIT_AT>
-__global__ __launch_bounds__(256, 1) void gemm_lin4_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 512 * 128];
-    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    constexpr int GM = 4;
-    const int width = GM * p.tiles_n;
-    const int grp = wg / width, rem = wg - grp * width;
-    const int first = grp * GM;
-    const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
-    const int tn = rem / gsz, tm = first + (rem - tn * gsz);
-    gemm_lin4_body<T, WAIT_AT>(p, smem, tm * 256, tn * 256);
-}
-
 template <typename T, int BM, int WN, int WM, int DMA_SPLIT, int WAIT_AT>
 __global__ __launch_bounds__(512, 2) void gemm_lin_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * (256 + BM) * 128];
@@ -388,10 +216,6 @@ __global__ __launch_bounds__(512, 2) void gemm_lin_kernel(const GemmParams p) {
 template <typename T>
 static int launch_lin(const GemmParams& p, int bm, int form, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(512);
-    if (bm == 256 && form == 2 && p.wide && !p.vt && !p.out8) {      // 4 waves of 128x128 (16-byte epilogue only, no transposed part)
-        hipLaunchKernelGGL((gemm_lin4_kernel<T, 2>), grid, dim3(256), 0, st, p);
-        return 0;
-    }
     if (bm == 192) hipLaunchKernelGGL((gemm_lin_kernel<T, 192, 4, 2, 0, 2>), grid, block, 0, st, p);
     else if (form == 0) hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 0, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 1, 2>), grid, block, 0, st, p);

@@ -20,7 +20,7 @@ def hint(v, bn, bm):
 
 
 VARIANTS = [("r256x256", hint(1, 256, 256)), ("r128x256", hint(1, 128, 256)), ("p128x64", hint(2, 128, 64)), ("h256f0", hint(5, 256, 256)),
-            ("h256f1", hint(5, 256, 257)), ("h4g", hint(5, 256, 258)), ("h192", hint(5, 256, 192)), ("r128x128", hint(1, 128, 128))]
+            ("h256f1", hint(5, 256, 257)), ("h192", hint(5, 256, 192)), ("r128x128", hint(1, 128, 128))]
 
 
 def main():
