@@ -23,15 +23,18 @@
 // its partner's MFMAs; the 4-wave 128x128-per-wave form measured 887-913 TFLOP/s on the 3072x10240x1280 GEGLU against 989-1027 for the
 // 8-wave forms, profiles/r04_gemm_probe_h4_vs_h5_v1.log, and the same geometry fed by plain buffer loads + ds_write_b128 instead of LDS-DMA
 // (fire-and-forget issue, a whole k-tile for the data to land) 855 against 1024, profiles/r04_gemm_probe_h4g_buffer_load_form.log: one wave
-// per SIMD is not held back by the DMA issue but by having nobody to cover ANY of its waits -- both removed, kept in history):
+// per SIMD is not held back by the DMA issue but by having nobody to cover ANY of its waits -- both removed, kept in history).
+// What bounds the 8-wave loop (profiles/r04_gemm_diag_k_frozen_no_dma.log, 8192^3): with NO operand delivery inside the loop it runs 1599
+// TFLOP/s = hipBLASLt's whole kernel (1616); every k-tile re-reading tile 0 (L2-hot) 1403; the real thing 1323.  So the fragment reads,
+// MFMAs and the barrier are at the library's level, the delivery costs 12 % even L2-hot and L2 misses another 6 %.  Staging the same
+// pieces through registers (buffer_load_b128 in step 0, ds_write_b128 in step 2) instead of LDS-DMA is 3-4 % slower on every shape
+// (profiles/r04_gemm_probe_h5v_register_staged.log) -- removed too:
 //   256 x 256 : 2 (n) x 4 (m) waves of 128 x 64
 //   256 x 192 : 4 (n) x 2 (m) waves of  64 x 96   -- 3072 x 3840 (fused QKV) and 9216 x 1280 give 240 tiles of it (one per CU, 94 % of the
 //                                                    chip) where 256 x 256 gives 180 (70 %)
 #include "gemm_common.cuh"
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T, int BM, int WN, int WM, int DMA_SPLIT, int WAIT_AT, bool TR, int DBG = 0, bool VG = false>
+template <typename T, int BM, int WN, int WM, int DMA_SPLIT, int WAIT_AT, bool TR>
 __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     constexpr int BN = 256, NW = WN * WM;
@@ -64,31 +67,11 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, c
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
     char* const dW = smem + wave * (PWW * 1024);         // + buffer * BUF + piece * 1024
     char* const dX = smem + OPW + wave * (PWX * 1024);
-    // DBG (measurement only, wrong results): 1 = every k-tile re-reads tile 0 (operands always L2-hot), 2 = no DMA inside the loop
     auto dma_w = [&](int i, int buf_off, uint32_t koff) {
-        if constexpr (DBG == 2) { if (koff) return; }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(dW + buf_off + i * 1024), 16, w_off[i], DBG == 1 ? 0u : koff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(dW + buf_off + i * 1024), 16, w_off[i], koff, 0, 0);
     };
     auto dma_x = [&](int i, int buf_off, uint32_t koff) {
-        if constexpr (DBG == 2) { if (koff) return; }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(dX + buf_off + i * 1024), 16, x_off[i], DBG == 1 ? 0u : koff, 0, 0);
-    };
-
-    // VG: the same pieces through registers -- buffer_load_b128 into a staging register in step 0, ds_write_b128 to the same lane-linear LDS
-    // position in step 2 (the LDS image is identical), instead of LDS-DMA: an LDS-DMA piece costs its wave 60-185 issue cycles next to MFMAs
-    // and ds_reads (/opt/skills/guides/MI355X_MICROARCH.md), a plain load ~one slot and its ds_write 13
-    u32x4 stg[PWW + PWX];
-    auto ld_all = [&](uint32_t koff) {
-#pragma unroll
-        for (int i = 0; i < PWW; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], koff, 0);
-#pragma unroll
-        for (int i = 0; i < PWX; ++i) stg[PWW + i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[i], koff, 0);
-    };
-    auto st_all = [&](int buf_off) {
-#pragma unroll
-        for (int i = 0; i < PWW; ++i) *(u32x4*)(dW + buf_off + i * 1024 + lane * 16) = stg[i];
-#pragma unroll
-        for (int i = 0; i < PWX; ++i) *(u32x4*)(dX + buf_off + i * 1024 + lane * 16) = stg[PWW + i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(dX + buf_off + i * 1024), 16, x_off[i], koff, 0, 0);
     };
 
     // ---- fragment addresses: row l31 of the wave's sub-tile, chunk (2s + u) ^ swizzle; 32-row groups are immediate offsets ----
@@ -126,12 +109,11 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, c
     constexpr int NRD = NI + MI;                         // fragment reads per k-step (6 | 5)
     // pin one k-step: every gap starts with 1 MFMA; the first `nrd` gaps carry 1 DS read, the LAST `nv` gaps 1 VMEM (an LDS-DMA piece);
     // more pieces than gaps: a second one per gap from the front
-    auto pin = [&](int nrd, int nv, int nwr = 0) {
+    auto pin = [&](int nrd, int nv) {
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
             if (i < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // DS read
-            if (i < nwr) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // DS write
             if (i >= NMF - nv) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    // VMEM
             if (i < nv - NMF) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // VMEM (overflow)
         }
@@ -139,17 +121,11 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, c
 
     const int nt = p.Ktot >> 6;
     // ---- prologue: tile 0 -> buffer 0, its step-0 fragments -> set 0 ----
-    if constexpr (VG) {
-        ld_all(0u);
-        st_all(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
 #pragma unroll
-        for (int i = 0; i < PWW; ++i) dma_w(i, 0, 0u);
+    for (int i = 0; i < PWW; ++i) dma_w(i, 0, 0u);
 #pragma unroll
-        for (int i = 0; i < PWX; ++i) dma_x(i, 0, 0u);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    for (int i = 0; i < PWX; ++i) dma_x(i, 0, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_all(0, 0, 0);
@@ -158,43 +134,6 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, c
     for (int t = 0; t + 1 < nt; ++t) {
         const int nxt = cur ^ BUF;
         const uint32_t koff = (uint32_t)(t + 1) * 128u;
-        if constexpr (VG) {
-            // ---- step 0: fragments of step 1 + the loads of tile t+1 into registers, one per gap ----
-            read_all(1, 1, cur);
-            ld_all(koff);
-            mfma_range(0, 0, NMF);
-            pin(NRD, PWW + PWX);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- step 1 ----
-            read_all(0, 2, cur);
-            mfma_range(1, 0, NMF);
-            pin(NRD, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- step 2: fragments of step 3 + the registers go to the other LDS buffer (free since the barrier of tile t-1) ----
-            read_all(1, 3, cur);
-            st_all(nxt);
-            mfma_range(0, 0, NMF);
-            pin(NRD, 0, PWW + PWX);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- step 3: cross into tile t+1 ----
-            mfma_range(1, 0, WAIT_AT);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            read_all(0, 0, nxt);
-            mfma_range(1, WAIT_AT, NMF);
-#pragma unroll
-            for (int i = 0; i < NMF - WAIT_AT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (i == NMF - WAIT_AT - 1 && NRD > NMF - WAIT_AT) __builtin_amdgcn_sched_group_barrier(0x100, NRD - (NMF - WAIT_AT), 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-            continue;
-        }
         // ---- step 0 ----
         read_all(1, 1, cur);
 #pragma unroll
@@ -256,7 +195,7 @@ __device__ __forceinline__ void gemm_lin_body(const GemmParams& p, char* smem, c
     gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, nullptr);
 }
 
-template <typename T, int BM, int WN, int WM, int DMA_SPLIT, int WAIT_AT, int DBG = 0, bool VG = false>
+template <typename T, int BM, int WN, int WM, int DMA_SPLIT, int WAIT_AT>
 __global__ __launch_bounds__(512, 2) void gemm_lin_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * (256 + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
@@ -270,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void gemm_lin_kernel(const GemmParams p) {
         tn = rem / gsz; tm = first + (rem - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * 256;
-    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_lin_body<T, BM, WN, WM, DMA_SPLIT, WAIT_AT, true, DBG, VG>(p, smem, m0, n0);   // block-uniform: the V^T part of a fused QKV
-    else gemm_lin_body<T, BM, WN, WM, DMA_SPLIT, WAIT_AT, false, DBG, VG>(p, smem, m0, n0);
+    if (p.vt != nullptr && n0 >= p.vt_n0) gemm_lin_body<T, BM, WN, WM, DMA_SPLIT, WAIT_AT, true>(p, smem, m0, n0);   // block-uniform: the V^T part of a fused QKV
+    else gemm_lin_body<T, BM, WN, WM, DMA_SPLIT, WAIT_AT, false>(p, smem, m0, n0);
 }
 
 // Called by gemm_conv.hip's launch_gemm for tile_hint variant 5 (BN = 256, BM = 256 | 192); `form` (the low nibble of tile_hint's BM field) selects
@@ -282,10 +221,6 @@ __global__ __launch_bounds__(512, 2) void gemm_lin_kernel(const GemmParams p) {
 template <typename T>
 static int launch_lin(const GemmParams& p, int bm, int form, hipStream_t st) {
     const dim3 grid(p.tiles_n * p.tiles_m), block(512);
-    if (bm == 256 && form == 3) { hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 1, 2, 0, true>), grid, block, 0, st, p); return 0; }   // operands through registers
-    if (bm == 192 && form == 3) { hipLaunchKernelGGL((gemm_lin_kernel<T, 192, 4, 2, 0, 2, 0, true>), grid, block, 0, st, p); return 0; }
-    if (bm == 256 && form == 6) { hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 1, 2, 1>), grid, block, 0, st, p); return 0; }   // measurement only
-    if (bm == 256 && form == 7) { hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 1, 2, 2>), grid, block, 0, st, p); return 0; }   // measurement only
     if (bm == 192) hipLaunchKernelGGL((gemm_lin_kernel<T, 192, 4, 2, 0, 2>), grid, block, 0, st, p);
     else if (form == 0) hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 0, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 1, 2>), grid, block, 0, st, p);

@@ -820,7 +820,7 @@ def check_elementwise(B, h, w, dtype, dev, seed=0):
     return max(e1, e2, e3, e4)
 
 
-RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"), (_hint(5, 256, 259), "h5v"), (_hint(5, 256, 195), "h192v"),
+RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
               (_hint(3, 256, 256), "q256x256"), (_hint(2, 256, 256), "p256x256"), (_hint(2, 128, 256), "p128x256"), (_hint(2, 128, 64), "p128x64"), (_hint(2, 64, 64), "p64x64"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))

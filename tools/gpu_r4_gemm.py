@@ -20,10 +20,7 @@ def hint(v, bn, bm):
 
 
 VARIANTS = [("r256x256", hint(1, 256, 256)), ("r128x256", hint(1, 128, 256)), ("p128x64", hint(2, 128, 64)), ("h256f0", hint(5, 256, 256)),
-            ("h256f1", hint(5, 256, 257)), ("h256v", hint(5, 256, 259)), ("h192", hint(5, 256, 192)), ("h192v", hint(5, 256, 195)), ("r128x128", hint(1, 128, 128))]
-
-if os.environ.get("IDMVTON_GEMM_DIAG") == "1":          # measurement-only forms of the hand-scheduled loop (WRONG results by design): every k-tile
-    VARIANTS += [("diag_k_frozen", hint(5, 256, 262)), ("diag_no_dma", hint(5, 256, 263))]   # re-reads tile 0 (always L2-hot) / no DMA in the loop
+            ("h256f1", hint(5, 256, 257)), ("h192", hint(5, 256, 192)), ("r128x128", hint(1, 128, 128))]
 
 
 def main():
