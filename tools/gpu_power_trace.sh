@@ -1,15 +1,16 @@
 #!/bin/bash
 # shader clock / socket power sampled every 0.25 s while bench.py runs: the evidence behind "the loop is power-limited" (DESIGN §6).
-# bash tools/gpu_power_trace.sh [tag]
+# bash tools/gpu_power_trace.sh [tag] [perf level | ""] [extra bench.py arguments, e.g. "--dtype f16"]
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 TAG=${1:-power}
 LEVEL=${2:-}                                    # optional: a rocm-smi performance level to try for the run (auto afterwards)
+EXTRA=${3:-}
 [ -n "$LEVEL" ] && { rocm-smi --setperflevel $LEVEL 2>&1 | grep -v "^$" | head -5; }
 rocm-smi --showperflevel --showmaxpower --showpower --showclocks > $O/${TAG}_smi_idle.txt 2>&1
 ( while true; do rocm-smi --showpower --showclocks --showtemp --json 2>/dev/null | tr -d '\n'; echo; sleep 0.25; done ) > $O/${TAG}_smi_samples.jsonl &
 SMI=$!
-timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/${TAG}_bench.json
+timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-fp16-leg $EXTRA 2>/dev/null | tail -1 > $O/${TAG}_bench.json
 kill $SMI
 [ -n "$LEVEL" ] && rocm-smi --setperflevel auto > /dev/null 2>&1
 python - "$O/${TAG}_smi_samples.jsonl" "$O/${TAG}_bench.json" <<'PY' | tee $O/${TAG}_summary.txt
