@@ -394,13 +394,14 @@ static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
 }
 
 // gemm_lin.hip: the hand-scheduled Linear main loop (variant 5: 256x256 as 8 waves x 128x64, 256x192 as 8 waves x 64x96)
-int launch_gemm_lin(const GemmParams& p, bool bf16, int bm, int form, hipStream_t st);
+int launch_gemm_lin(const GemmParams& p, bool bf16, int bm, int form, int grid_cap, hipStream_t st);
 
 template <typename T>
 static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool lin, hipStream_t st) {
     GemmParams p = p0;
     int form = 0;
-    if (variant == 5) { form = bm & 15; bm &= ~15; }       // placement form under measurement: low nibble of the BM field
+    int grid_cap = 0;                                        // tests only (bit 14 of the BM field): 5 persistent workgroups, so small shapes walk several tiles each
+    if (variant == 5) { form = bm & 15; grid_cap = (bm & 0x4000) ? 5 : 0; bm &= ~(15 | 0x4000); }   // placement form: low nibble of the BM field
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tiles_m = (p.M + bm - 1) / bm;
     if (p.mode == IDMVTON_EPI_XATTN) {                   // tiles whose waves own 64 columns: 128x64, 128x128 (2x2 waves), 128x256 (2x4)
@@ -440,7 +441,7 @@ static int launch_gemm(const GemmParams& p0, int variant, int bn, int bm, bool l
         else launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);              // 8-byte epilogue, a V^T part or e4m3 output: the 8-wave tile
     } else if (variant == 5) {                           // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
         if (!(bn == 256 && (bm == 256 || bm == 192))) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 5 is the 256x256 / 256x192 tile");
-        if (lin && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, std::is_same<T, bf16_t>::value, bm, form, st);
+        if (lin && !p.ln_rowstats && !p.rs_counter) launch_gemm_lin(p, std::is_same<T, bf16_t>::value, bm, form, grid_cap, st);
         else if (bm == 256) launch_cfg<T, 256, 256, 2, 4, 2, true, 2>(p, lin, st);
         else {                                           // 256x192 exists only hand-scheduled: the same launch on the 128x256 ring tile
             p.tiles_n = (p.N + 127) / 128; p.tiles_m = (p.M + 255) / 256;
