@@ -95,7 +95,8 @@ typedef struct {
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
                                     variant 1 with register-prefetched fragments on every tile; variant 3 = 256x256 as 4 waves of 128x128 (AGPR
                                     accumulators, one wave per SIMD); variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
-                                    of the BM field = placement form 0 | 1) and 256x192.  Bit 15
+                                    of the BM field = placement form 0 | 1; bit 14 of it, tests only: 5 persistent workgroups) and 256x192 -- a PERSISTENT kernel:
+                                    min(tiles, CUs) workgroups walk the tile raster.  Bit 15
                                     (0x8000) forces the 8-byte epilogue (measurement only; default: 16-byte accesses when every
                                     epilogue operand is 16-byte aligned with strides / N multiples of 8).
                                     Filled from the per-shape tuning table (idm-vton_amd/tune_gfx950.json). */
