@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 4, call R: 256x256 as 4 waves of 128x128 fed by buffer loads + ds_write (tile_hint variant 5, form 2): kernel checks, then the
+# (ran at commit 5efd548: the form it measures was removed afterwards and lives in that commit)
 # GEMM probe against the 8-wave hand-scheduled forms, the compiler tiles and hipBLASLt.
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out; mkdir -p $O

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 4, call T: the 8-wave hand-scheduled loop with its operands staged through registers (buffer_load_b128 -> ds_write_b128) instead of
+# (ran at commit 7b6465b: the measurement forms were removed afterwards and live in that commit)
 # LDS-DMA (variant 5 form 3): kernel checks, then the probe next to the DMA forms and hipBLASLt.
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out; mkdir -p $O
