@@ -192,7 +192,10 @@ __device__ __forceinline__ void gemm_lin_persistent(const GemmParams& p, char* s
             // ---- step 3: cross into tile t+1 ----
             mfma_range(1, 0, WAIT_AT);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // vmcnt: this wave's pieces of k-tile t+1 have landed.  lgkmcnt: ALL its fragment reads of k-tile t are done before anybody may
+            // refill that buffer (they were issued a k-step ago; with 3 activation fragments per step the first WAIT_AT MFMAs alone would leave
+            // the last one formally in flight across the barrier)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
