@@ -24,6 +24,7 @@ def main():
         for _ in range(reps):
             ops.linear(x, w, out=o, tile_hint=H(1, 256, 256))
             ops.linear(x, w, out=o, tile_hint=H(1, 128, 256))
+            ops.linear(x, w, out=o, tile_hint=H(5, 256, 257))       # round 4: the hand-scheduled persistent loop (gemm_lin_kernel)
             torch.matmul(x, wt, out=o)
     torch.cuda.synchronize()
     print("done")
