@@ -1,5 +1,7 @@
 """rocprofv3 --pmc rocpd databases (*_results.db) -> table per (kernel, grid): mean of every counter over its dispatches, plus the
-mean duration when --kernel-trace was on.   python tools/pmc_db_by_kernel.py <dir-or-db> [...] [--match substr]"""
+mean duration when --kernel-trace was on.   python tools/pmc_db_by_kernel.py <dir-or-db> [...] [--match substr] [--split-duration]
+--split-duration: persistent kernels launch the same grid for every shape; add the power-of-two bucket of the dispatch duration to the key so that
+different shapes of one kernel get their own rows."""
 import glob
 import os
 import re
@@ -15,8 +17,9 @@ def short(name):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for a in sys.argv[1:] if not a.startswith("--") and (sys.argv[sys.argv.index(a) - 1] != "--match")]
     match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else None
+    split = "--split-duration" in sys.argv
     dbs = []
     for a in args:
         dbs += [a] if a.endswith(".db") else glob.glob(os.path.join(a, "**", "*_results.db"), recursive=True)
@@ -30,7 +33,7 @@ def main():
         for name, grid, wg, cn, val, t0, t1 in c.execute(q):
             if match and match not in name:
                 continue
-            key = (short(name), int(grid) // max(int(wg), 1))
+            key = (short(name) + (f" ~2^{max(t1 - t0, 1).bit_length()}ns" if split else ""), int(grid) // max(int(wg), 1))
             a = agg.setdefault(key, {})
             e = a.setdefault(cn, [0, 0.0])
             e[0] += 1
