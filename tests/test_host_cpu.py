@@ -35,6 +35,44 @@ def test_arg_validation_without_gpu():
         ffi.call("idmvton_gemm_conv", a, 0)
 
 
+def test_fp8_output_contract_is_checked_on_the_host():
+    """IDMVTON_IO_OUT_F8 (C ABI v7: the projection writes idmvton_attn_f8's e4m3 operands itself): plain 16-byte epilogue only, whole 64-key
+    tiles per batch element, positive power-of-two scales -- refused before any launch otherwise (the pointers below are never dereferenced)."""
+    from idm_vton_amd import ffi
+
+    def base():
+        a = ffi.GemmConvArgs()
+        a.dtype, a.w, a.N, a.Ktot, a.nseg = ffi.BF16, 0x10000, 256, 64, 1
+        a.seg[0].ptr, a.seg[0].bytes, a.seg[0].pitch, a.seg[0].coff, a.seg[0].len = 0x20000, 128 * 64 * 2, 64, 0, 64
+        a.M, a.Ho, a.Wo, a.Hi, a.Wi, a.stride = 128, 1, 128, 1, 128, 1
+        a.out, a.ldo = 0x30000, 128
+        a.vt, a.vt_n0, a.vt_tokens = 0x40000, 128, 64
+        a.io_flags, a.f8_out_scale, a.f8_vt_scale = ffi.IO_OUT_F8, 4.0, 4.0
+        return a
+
+    a = base()
+    a.res, a.ldr = 0x50000, 128
+    with pytest.raises(RuntimeError, match="IDMVTON_IO_OUT_F8 needs the plain 16-byte epilogue"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    a = base()
+    a.mode = ffi.EPI_GELU
+    with pytest.raises(RuntimeError, match="IDMVTON_IO_OUT_F8"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    a = base()
+    a.M, a.Wo, a.Wi, a.vt_tokens = 96, 96, 96, 32
+    a.seg[0].bytes = 96 * 64 * 2
+    with pytest.raises(RuntimeError, match="vt_tokens"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    a = base()
+    a.f8_vt_scale = 0.0
+    with pytest.raises(RuntimeError, match="scales > 0"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    a = base()
+    a.io_flags = ffi.IO_OUT_F8 | ffi.IO_OUT_F32
+    with pytest.raises(RuntimeError, match="IDMVTON_IO_OUT_F8"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+
+
 def test_ops_refuse_cpu_tensors():
     from idm_vton_amd import ops
     x, w = torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16)
