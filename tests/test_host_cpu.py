@@ -73,6 +73,57 @@ def test_fp8_output_contract_is_checked_on_the_host():
         ffi.call("idmvton_gemm_conv", a, 0)
 
 
+def test_fused_cross_attention_and_upsample_contracts_are_checked_on_the_host():
+    """IDMVTON_EPI_XATTN (the cross-attention as attn2.to_q's epilogue) and `ups` with the skip tensor's size (diffusers' upsample_size): the shapes
+    the kernels cannot serve are refused before any launch."""
+    import ctypes as C
+    from idm_vton_amd import ffi
+
+    def lin():
+        a = ffi.GemmConvArgs()
+        a.dtype, a.w, a.N, a.Ktot, a.nseg = ffi.BF16, 0x10000, 128, 64, 1
+        a.seg[0].ptr, a.seg[0].bytes, a.seg[0].pitch, a.seg[0].coff, a.seg[0].len = 0x20000, 128 * 64 * 2, 64, 0, 64
+        a.M, a.Ho, a.Wo, a.Hi, a.Wi, a.stride = 128, 1, 128, 1, 128, 1
+        a.out, a.ldo = 0x30000, 128
+        return a
+
+    def xa(nk=77, tokens=64, k_rows=96, ldvt=80):
+        x = ffi.XAttn()
+        x.nseg, x.tokens, x.ip_scale = 1, tokens, 1.0
+        x.k[0], x.vt[0], x.ldk[0], x.ldvt[0], x.nk[0], x.k_rows[0] = 0x40000, 0x50000, 128, ldvt, nk, k_rows
+        return x
+
+    a = lin()
+    a.mode = ffi.EPI_XATTN                                                   # mode without its descriptor
+    with pytest.raises(RuntimeError, match="needs `xattn`"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    for kw, msg in ((dict(nk=97, k_rows=128, ldvt=112), "nk=97"), (dict(k_rows=77), "k_rows=77"), (dict(tokens=48), "xattn.tokens=48")):
+        a = lin()
+        x = xa(**kw)
+        a.mode, a.xattn = ffi.EPI_XATTN, C.pointer(x)
+        with pytest.raises(RuntimeError, match=msg):
+            ffi.call("idmvton_gemm_conv", a, 0)
+    a = lin()
+    x = xa()
+    a.mode, a.xattn, a.bias = ffi.EPI_XATTN, C.pointer(x), 0x60000           # nothing else may sit in that epilogue
+    with pytest.raises(RuntimeError, match="nothing else in its epilogue"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    a = lin()
+    x = xa()
+    a.xattn = C.pointer(x)                                                   # descriptor without the mode
+    with pytest.raises(RuntimeError, match="without mode IDMVTON_EPI_XATTN"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    # nearest-2x upsample fused into a 3x3 convolution: the output grid is 2Hi x 2Wi or one short of it, stride 1
+    a = ffi.GemmConvArgs()
+    a.dtype, a.w, a.N, a.Ktot, a.nseg = ffi.BF16, 0x10000, 64, 64, 1
+    a.seg[0].ptr, a.seg[0].bytes, a.seg[0].pitch, a.seg[0].coff, a.seg[0].len = 0x20000, 4 * 4 * 64 * 2, 64, 0, 64
+    a.Hi, a.Wi, a.Ho, a.Wo, a.stride, a.ups = 4, 4, 6, 8, 1, 1
+    a.M = a.Ho * a.Wo
+    a.out, a.ldo = 0x30000, 64
+    with pytest.raises(RuntimeError, match="ups=1 needs stride 1 and an output grid"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+
+
 def test_ops_refuse_cpu_tensors():
     from idm_vton_amd import ops
     x, w = torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16)
