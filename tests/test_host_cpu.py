@@ -124,6 +124,38 @@ def test_fused_cross_attention_and_upsample_contracts_are_checked_on_the_host():
         ffi.call("idmvton_gemm_conv", a, 0)
 
 
+def test_split_precision_entry_points_check_their_arguments_on_the_host():
+    """The split-precision VAE path's entry points (C ABI v6: idmvton_split, the flags of idmvton_groupnorm / idmvton_layout, y_split / n_valid of
+    idmvton_softmax_rows) refuse what they cannot do before any launch."""
+    from idm_vton_amd import ffi
+    a = ffi.SplitArgs()
+    a.dtype, a.mode, a.rows, a.cols, a.src, a.lds, a.dst, a.ldd = ffi.BF16, 7, 8, 64, 0x10000, 64, 0x20000, 128
+    with pytest.raises(RuntimeError, match="split: mode 7"):
+        ffi.call("idmvton_split", a, 0)
+    a.mode, a.rows, a.ldd = ffi.SPLIT_W3T, 12, 64
+    with pytest.raises(RuntimeError, match="W3T needs rows"):
+        ffi.call("idmvton_split", a, 0)
+    g = ffi.GroupNormArgs()
+    g.dtype, g.B, g.HW, g.C, g.groups, g.C1 = ffi.BF16, 1, 16, 64, 32, 64
+    g.x, g.gamma, g.beta, g.y, g.stats, g.eps = 0x10000, 0x20000, 0x30000, 0x40000, 0x50000, 1e-6
+    g.stats_doubles = ffi.lib().idmvton_groupnorm_stats_doubles(1, 16, 64, 32)
+    g.flags = ffi.GN_X_F32                                                   # the split-precision form is all three flags or none
+    with pytest.raises(RuntimeError, match="groupnorm: flags=1"):
+        ffi.call("idmvton_groupnorm", g, 0)
+    l = ffi.LayoutArgs()
+    l.dtype, l.B, l.C, l.HW, l.cpad, l.to_nhwc, l.src, l.dst, l.scale = ffi.BF16, 1, 3, 16, 8, 0, 0x10000, 0x20000, 1.0
+    l.flags = ffi.LAYOUT_SPLIT                                               # [hi | lo] pairs are an NHWC (to_nhwc) output form
+    with pytest.raises(RuntimeError, match="layout"):
+        ffi.call("idmvton_layout", l, 0)
+    m = ffi.SoftmaxArgs()
+    m.dtype, m.rows, m.n, m.ld, m.x, m.scale, m.n_valid = ffi.BF16, 4, 64, 64, 0x10000, 1.0, 65
+    with pytest.raises(RuntimeError, match="n_valid=65"):
+        ffi.call("idmvton_softmax_rows", m, 0)
+    m.n_valid, m.y_split, m.ldy = 0, 0x20000, 64                            # the pair needs 2n columns
+    with pytest.raises(RuntimeError, match="y_split ldy=64"):
+        ffi.call("idmvton_softmax_rows", m, 0)
+
+
 def test_ops_refuse_cpu_tensors():
     from idm_vton_amd import ops
     x, w = torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16)
