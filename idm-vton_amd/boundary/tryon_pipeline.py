@@ -147,6 +147,22 @@ class StableDiffusionXLInpaintPipeline:
     def device(self):
         return self._device
 
+    # ------------------------------------------------------------------------------------------ memory toggles of the call surface
+    # /root/reference/src/tryon_pipeline.py:427-457 forward these to the VAE.  The HIP VAE has nothing to switch: it already walks its batch in
+    # chunks below the 2 GiB a buffer descriptor addresses (idm_vton_amd/vae.py) and 288 GB of HBM need no tiling; the methods exist so that a
+    # caller that toggles them keeps working, and they record the request on the VAE like diffusers does (`use_slicing` / `use_tiling`).
+    def enable_vae_slicing(self):
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    def enable_vae_tiling(self):
+        self.vae.enable_tiling()
+
+    def disable_vae_tiling(self):
+        self.vae.disable_tiling()
+
     @property
     def guidance_scale(self):
         return self._guidance_scale

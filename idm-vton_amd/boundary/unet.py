@@ -173,6 +173,41 @@ class _UNetBase(nn.Module):
                 m.set_processor(processor)
         self._hip_key = None
 
+    def set_default_attn_processor(self):
+        """Reference :854-867: drop custom processors.  The stock processor of this boundary is AttnProcessor2_0 (TryonNet's attn2 layers then
+        lose their IP-Adapter branch, exactly as the reference's would)."""
+        self.set_attn_processor(AttnProcessor2_0(), _remove_lora=True)
+
+    def set_attention_slice(self, slice_size):
+        """Reference :869-932 (sliced attention to save memory).  No-op by construction: the HIP attention kernel is blockwise (online softmax
+        over 64-key tiles, csrc/attention.hip) and never materialises a [queries x keys] score matrix, so there is nothing to slice; the
+        argument is validated like the reference's and recorded."""
+        if not (slice_size in ("auto", "max") or isinstance(slice_size, int) or
+                (isinstance(slice_size, (list, tuple)) and all(isinstance(v, int) for v in slice_size))):
+            raise ValueError(f"slice_size {slice_size!r} must be 'auto', 'max', an int or a list of ints")
+        self.attention_slice = slice_size
+
+    def fuse_qkv_projections(self):
+        """Reference :970-991.  The HIP engine ALWAYS runs attn1's q|k|v as one GEMM and attn2's k|v as one (prepared weight layouts,
+        idm_vton_amd/unet.py:_prep), whatever this flag says: same arithmetic per output channel, so the call only checks what the reference
+        checks and records the request."""
+        for proc in self.attn_processors.values():
+            if "Added" in proc.__class__.__name__:
+                raise ValueError("`fuse_qkv_projections()` is not supported for models having added KV projections.")
+        self.original_attn_processors = self.attn_processors
+
+    def unfuse_qkv_projections(self):
+        """Reference :993-1004."""
+        if getattr(self, "original_attn_processors", None) is not None:
+            self.set_attn_processor(self.original_attn_processors)
+
+    def enable_freeu(self, s1, s2, b1, b2):
+        """Reference :938-960 rescales skip / backbone features in the up blocks -- different arithmetic that no IDM-VTON script enables."""
+        raise NotImplementedError("FreeU is not used on the try-on path and not supported by the HIP forward")
+
+    def disable_freeu(self):
+        return None
+
     # ------------------------------------------------------------------------------------------ engine
     def _check_fusable(self):
         scale = None

@@ -78,6 +78,23 @@ class AutoencoderKL(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    # diffusers AutoencoderKL.enable_slicing / enable_tiling (called through the pipeline's enable_vae_slicing / enable_vae_tiling,
+    # /root/reference/src/tryon_pipeline.py:427-457).  Slicing is what the HIP VAE does anyway (batch elements are independent; the batch is
+    # walked in chunks that fit a 32-bit buffer descriptor): identical results.  Tiling in diffusers is an APPROXIMATION (overlapping tiles
+    # blended) that exists to fit small GPUs; here the request is recorded and the exact untiled result is computed -- 288 GB of HBM hold a
+    # 1024x768 decode (4.3 GB of activations) many times over.
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def enable_tiling(self, use_tiling=True):
+        self.use_tiling = bool(use_tiling)
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
     def hip_engine(self):
         ffi.lib()
         p0 = next(self.parameters())

@@ -502,9 +502,10 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
                   IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN is a plain Linear with N %% 64 == 0 and nothing else in its epilogue");
         CHECK_ARG(x->tokens > 0 && x->tokens % 32 == 0 && a->M % x->tokens == 0, IDMVTON_E_SHAPE, "gemm_conv: xattn.tokens=%d (rows per batch element, a multiple of 32 dividing M=%d)", x->tokens, a->M);
         for (int s = 0; s < x->nseg; ++s) {
-            CHECK_ARG(x->k[s] && x->vt[s] && x->nk[s] > 0 && x->nk[s] <= 96 && x->k_rows[s] >= ((x->nk[s] + 31) & ~31) && x->ldk[s] >= a->N && x->ldk[s] % 8 == 0 &&
+            const int nk_max = s == 0 ? 96 : 32;         // xattn.cuh holds 3 K blocks / 6 V^T steps for segment 0 (text) and 1 / 2 for segment 1 (image prompt)
+            CHECK_ARG(x->k[s] && x->vt[s] && x->nk[s] > 0 && x->nk[s] <= nk_max && x->k_rows[s] >= ((x->nk[s] + 31) & ~31) && x->ldk[s] >= a->N && x->ldk[s] % 8 == 0 &&
                       x->ldvt[s] >= ((x->nk[s] + 15) & ~15) && x->ldvt[s] % 8 == 0 && (((uintptr_t)x->k[s] | (uintptr_t)x->vt[s]) & 15) == 0, IDMVTON_E_SHAPE,
-                      "gemm_conv: xattn segment %d: nk=%d (<= 96) k_rows=%d (>= round32(nk)) ldk=%d ldvt=%d (>= round16(nk))", s, x->nk[s], x->k_rows[s], x->ldk[s], x->ldvt[s]);
+                      "gemm_conv: xattn segment %d: nk=%d (<= %d) k_rows=%d (>= round32(nk)) ldk=%d ldvt=%d (>= round16(nk))", s, x->nk[s], nk_max, x->k_rows[s], x->ldk[s], x->ldvt[s]);
             p.xa.k[s] = x->k[s]; p.xa.vt[s] = x->vt[s]; p.xa.ldk[s] = x->ldk[s]; p.xa.ldvt[s] = x->ldvt[s]; p.xa.nk[s] = x->nk[s]; p.xa.krows[s] = x->k_rows[s];
         }
         p.xa.nseg = x->nseg; p.xa.tokens = x->tokens; p.xa.vchan = a->N; p.xa.ip_scale = x->ip_scale;

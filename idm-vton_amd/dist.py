@@ -111,9 +111,16 @@ class local_lock:
             return self
         import fcntl
         import tempfile
-        path = os.path.join(tempfile.gettempdir(), f"idmvton_{os.environ.get('MASTER_PORT', '0')}_{self.name}.lock")
-        self.f = open(path, "w")
-        fcntl.flock(self.f, fcntl.LOCK_EX)
+        # per user and per job: a second user on a shared node with the same port must not hit a file it cannot open
+        uid = os.getuid() if hasattr(os, "getuid") else 0
+        path = os.path.join(tempfile.gettempdir(), f"idmvton_{uid}_{os.environ.get('MASTER_PORT', '0')}_{self.name}.lock")
+        try:
+            self.f = os.fdopen(os.open(path, os.O_CREAT | os.O_RDWR, 0o666), "a")     # never truncates a file another rank holds
+            fcntl.flock(self.f, fcntl.LOCK_EX)
+        except OSError:                                  # no usable lock file: run unstaggered rather than die before warm-up
+            if self.f is not None:
+                self.f.close()
+            self.f = None
         return self
 
     def __exit__(self, *exc):

@@ -102,6 +102,12 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     accumulator order (xattn_q_weight()).
     vt: columns >= vt_n0 are written transposed ([B][N - vt_n0][vt_tokens]); vt_perm=True (default) writes them in the attention
     kernel's key order (see key_order()), False as a plain transpose."""
+    if f8 is not None:
+        # the C side's IDMVTON_IO_OUT_F8 contract (plain 16-byte epilogue): refuse here what would otherwise be silently dropped with the flags
+        if res is not None or rowbias is not None or geglu or gelu or quick_gelu or (bias is not None and bias.dtype == torch.float32):
+            raise ValueError("gemm_conv(f8=...): no residual / rowbias / activation, and the bias in the storage dtype (not fp32)")
+        if vt is not None and vt_tokens % 64 != 0:
+            raise ValueError(f"gemm_conv(f8=...): vt_tokens must be a multiple of 64 (got {vt_tokens})")
     a = ffi.GemmConvArgs()
     a.dtype = _dt(w)
     N, Ktot = w.shape

@@ -106,7 +106,9 @@ class HipUNet:
             self.temb_slices[p] = (off, cout)
             off += cout
 
-        def prep_tf(p, ch, n_tf, heads):
+        def prep_tf(p, ch, n_tf, heads, level):
+            """level = index of the resolution the transformer runs at (0 = the latent size, +1 per Downsample2D): recorded from the
+            topology walk, not inferred from the channel count (block_out_channels may repeat a width)."""
             blocks = []
             for k in range(n_tf):
                 b = f"{p}.transformer_blocks.{k}"
@@ -124,28 +126,31 @@ class HipUNet:
                     d["ff1_w"], d["ff1_cv"] = ops.ln_fold_weights(d["ff1_w"], sd[f"{b}.norm3.weight"], sd[f"{b}.norm3.bias"])
                 d["p"] = b
                 blocks.append(d)
-            self.tf[p] = dict(blocks=blocks, ch=ch, heads=heads)
+            self.tf[p] = dict(blocks=blocks, ch=ch, heads=heads, level=level)
 
+        level = 0
         for i, blk in enumerate(self.topo["down"]):
             for j, (ci, co) in enumerate(blk["resnets"]):
                 prep_res(f"down_blocks.{i}.resnets.{j}", ci, co)
                 if blk["attn"]:
-                    prep_tf(f"down_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"])
+                    prep_tf(f"down_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"], level)
             if blk["down"]:
                 self.res[f"down_blocks.{i}.downsamplers.0.conv"] = _Conv(sd, f"down_blocks.{i}.downsamplers.0.conv")
+                level += 1
         m = self.topo["mid"]
         prep_res("mid_block.resnets.0", m["ch"], m["ch"])
-        prep_tf("mid_block.attentions.0", m["ch"], m["n_tf"], m["heads"])
+        prep_tf("mid_block.attentions.0", m["ch"], m["n_tf"], m["heads"], level)
         prep_res("mid_block.resnets.1", m["ch"], m["ch"])
         for i, blk in enumerate(self.topo["up"]):
-            if not self.tryon and not blk["attn"]:
-                continue                               # GarmentNet never executes non-attention up blocks
-            for j, (rin, skip, co) in enumerate(blk["resnets"]):
-                prep_res(f"up_blocks.{i}.resnets.{j}", rin + skip, co)
-                if blk["attn"]:
-                    prep_tf(f"up_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"])
+            if self.tryon or blk["attn"]:              # GarmentNet never executes non-attention up blocks
+                for j, (rin, skip, co) in enumerate(blk["resnets"]):
+                    prep_res(f"up_blocks.{i}.resnets.{j}", rin + skip, co)
+                    if blk["attn"]:
+                        prep_tf(f"up_blocks.{i}.attentions.{j}", blk["ch"], blk["n_tf"], blk["heads"], level)
+                if blk["up"]:
+                    self.res[f"up_blocks.{i}.upsamplers.0.conv"] = _Conv(sd, f"up_blocks.{i}.upsamplers.0.conv")
             if blk["up"]:
-                self.res[f"up_blocks.{i}.upsamplers.0.conv"] = _Conv(sd, f"up_blocks.{i}.upsamplers.0.conv")
+                level -= 1
         # transformer blocks in traversal order == GarmentNet feature order (unet_hacked_tryon.py:1254 running index)
         self.block_order = [blk for tf in self.tf.values() for blk in tf["blocks"]]
         self.temb_w = torch.cat(temb_w).contiguous()          # one GEMM for every resnet's time_emb_proj
@@ -319,7 +324,8 @@ class HipUNet:
         # (not for the timestep-batched GarmentNet at the 1280-channel level: at M = 9216 the plain projection runs on the 256x256 tile at twice
         #  the rate of the 128-column tiles the fused form needs -- 55 us for the two launches against 60 fused, profiles/r04_xattn_probe_*.log)
         if self.fuse_xattn and not fuse and N % 32 == 0 and not (C >= 1280 and M >= 8192) and \
-                all(sg["nk"] <= 96 and sg["k_rows"] >= (sg["nk"] + 31) // 32 * 32 for sg in xsegs):
+                all(sg["nk"] <= (96, 32)[i] and sg["k_rows"] >= (sg["nk"] + 31) // 32 * 32 for i, sg in enumerate(xsegs)):
+            # (96 text keys / 32 image-prompt keys are what the fused epilogue holds; a larger segment takes the two-launch path below)
             # attn2.to_q with the cross-attention as its epilogue (csrc/xattn.cuh): q never leaves the registers, no attention launch
             if "q2_xw" not in blk:
                 blk["q2_xw"] = ops.xattn_q_weight(sd[p + ".attn2.to_q.weight"])
@@ -386,8 +392,7 @@ class HipUNet:
         lv = [(h, w)]
         for _ in range(len(self.cfg.block_out_channels) - 1):
             lv.append(((lv[-1][0] + 1) // 2, (lv[-1][1] + 1) // 2))
-        ch2lv = {c: i for i, c in enumerate(self.cfg.block_out_channels)}
-        return [lv[ch2lv[tf["ch"]]][0] * lv[ch2lv[tf["ch"]]][1] for tf in self.tf.values() for _ in tf["blocks"]]
+        return [lv[tf["level"]][0] * lv[tf["level"]][1] for tf in self.tf.values() for _ in tf["blocks"]]
 
     def num_features(self):
         return sum(len(t["blocks"]) for t in self.tf.values())

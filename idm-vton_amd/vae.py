@@ -87,13 +87,19 @@ class HipVAE:
         if self.precise_decode:
             self._prep_precise({k: v.to(device=self.device, dtype=torch.float32) for k, v in state_dict.items()
                                 if k.startswith(("decoder.", "post_quant_conv."))})
-        sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items()}
+        # the split-precision decoder holds its own (hi, lo) weight pairs: the 16-bit copies of the decoder's weights and their padded conv
+        # objects would be dead memory on every rank, so they are only built for precise_decode=False
+        dec16 = not self.precise_decode
+        sd = {k: v.to(device=self.device, dtype=dtype) for k, v in state_dict.items()
+              if dec16 or not k.startswith(("decoder.", "post_quant_conv."))}
         self.sd = sd
         boc, L = cfg.block_out_channels, cfg.layers_per_block
         self.convs = {}
         self._gn_stats = torch.empty(ops.GN_STATS_DOUBLES, dtype=torch.float64, device=self.device)
 
         def res(p, cin, cout):
+            if p.startswith("decoder.") and not dec16:
+                return
             self.convs[p + ".conv1"] = _Conv(sd, p + ".conv1")
             self.convs[p + ".conv2"] = _Conv(sd, p + ".conv2", shortcut=(p + ".conv_shortcut") if cin != cout else None)
 
@@ -119,12 +125,13 @@ class HipVAE:
         lc = cfg.latent_channels
         self.quant_w = pad_k(sd["quant_conv.weight"].reshape(2 * lc, 2 * lc), 64)
         self.quant_b = sd["quant_conv.bias"].contiguous()
-        pq = torch.zeros(64, 64, dtype=dtype, device=self.device)
-        pq[:lc, :lc] = sd["post_quant_conv.weight"].reshape(lc, lc)
-        self.pq_w = pq
-        self.pq_b = torch.zeros(64, dtype=dtype, device=self.device)
-        self.pq_b[:lc] = sd["post_quant_conv.bias"]
-        self.convs["decoder.conv_in"] = _Conv(sd, "decoder.conv_in", cin_pad=64)
+        if dec16:
+            pq = torch.zeros(64, 64, dtype=dtype, device=self.device)
+            pq[:lc, :lc] = sd["post_quant_conv.weight"].reshape(lc, lc)
+            self.pq_w = pq
+            self.pq_b = torch.zeros(64, dtype=dtype, device=self.device)
+            self.pq_b[:lc] = sd["post_quant_conv.bias"]
+            self.convs["decoder.conv_in"] = _Conv(sd, "decoder.conv_in", cin_pad=64)
         rboc = list(reversed(boc))
         self.dec_plan, out = [], rboc[0]
         for i, c in enumerate(rboc):
@@ -137,9 +144,11 @@ class HipVAE:
             up = None
             if i != len(boc) - 1:
                 up = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                self.convs[up] = _Conv(sd, up)
+                if dec16:
+                    self.convs[up] = _Conv(sd, up)
             self.dec_plan.append((rs, up))
-        self.convs["decoder.conv_out"] = _Conv(sd, "decoder.conv_out", pad_out_to=4)
+        if dec16:
+            self.convs["decoder.conv_out"] = _Conv(sd, "decoder.conv_out", pad_out_to=4)
 
     # ---- blocks ----
     def _gn(self, x, name, silu):

@@ -76,7 +76,7 @@ typedef struct {
     int32_t nseg;
     const void* k[2]; int32_t ldk[2]; int32_t k_rows[2];
     const void* vt[2]; int32_t ldvt[2];
-    int32_t nk[2];               /* <= 96 */
+    int32_t nk[2];               /* nk[0] <= 96 (text), nk[1] <= 32 (image prompt): the fragment slots xattn.cuh holds per segment */
     int32_t tokens; float ip_scale;
 } idmvton_xattn;
 enum { IDMVTON_IO_RES_F32 = 1, IDMVTON_IO_OUT_F32 = 2, IDMVTON_IO_BIAS_F32 = 4, IDMVTON_IO_OUT_F8 = 8 };

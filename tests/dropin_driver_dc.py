@@ -7,9 +7,9 @@ boxes where /root/reference is absent (the GPU box):
 Test infrastructure.  The dataset class is a reduced stand-in for DresscodeTestDataset (:96-226): same directory layout
 (<category>/images/<id>_{0,1}.jpg, label_maps/<id>_4.png, keypoints/<id>_2.json, image-densepose/, dc_caption.txt, test_pairs_<order>.txt),
 same sample dict (c_name, im_name, image, cloth_pure, cloth, inpaint_mask, im_mask, caption, caption_cloth, pose_img).  Its agnostic mask
-is NOT the reference's get_agnostic (:232-352: ImageDraw arm strokes + cv2.dilate -- preprocessing, out of scope): it marks
-the garment + arm labels of the parse map and the box the shoulder / wrist keypoints span, which gives the pipeline a mask of the same
-type, range and rough shape; the parity test replays exactly what crossed the engine boundary, whatever the mask is.
+is the product's OpenCV-free get_agnostic (idm_vton_amd/dresscode.py), which tests/test_dresscode_cpu.py holds bit-equal to the
+reference's method (:231-352) -- so the mask that reaches the engine here is the one the unmodified script would hand it; the parity
+test replays exactly what crossed the engine boundary.
 --dump_call F: (test hook) save what the FIRST pipe(..., output_type="latent") call handed to the engine, and the latents it returned."""
 import argparse
 import json
@@ -46,15 +46,10 @@ class SynthDresscode(data.Dataset):
         return len(self.pairs)
 
     def _agnostic(self, parse, pose):
-        """1 = keep, 0 = repaint (the reference multiplies the image by it and passes 1 - it as the inpaint mask, :207-208)."""
-        repaint = np.isin(parse, GARMENT_LABELS[self.category])
-        pts = pose[[2, 5, 4, 7], :2] * np.array([self.w / 384.0, self.h / 512.0])       # shoulders and wrists, rescaled as :188-189
-        pts = pts[(pts > 1).all(1)]
-        if len(pts):
-            x0, y0 = np.floor(pts.min(0)).astype(int)
-            x1, y1 = np.ceil(pts.max(0)).astype(int)
-            repaint[max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = True
-        return torch.from_numpy(~repaint).float().unsqueeze(0)
+        """1 = keep, 0 = repaint (the reference multiplies the image by it and passes 1 - it as the inpaint mask, :207-208): the product's
+        get_agnostic (idm_vton_amd/dresscode.py), bit-equal to the reference's method (:231-352; tests/test_dresscode_cpu.py)."""
+        from idm_vton_amd.dresscode import get_agnostic
+        return get_agnostic(parse, pose, self.category, (self.w, self.h)).float()
 
     def __getitem__(self, i):
         im, c = self.pairs[i]

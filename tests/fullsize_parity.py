@@ -14,6 +14,8 @@ values (one seeded bf16-rounded set, exactly representable in fp16 and fp32) and
   hip_f16, hip_bf16          the product, storage fp16 / bf16 (default: the transformer residual stream is rounded to the storage dtype
                              after every add, as the reference's autocast does)
   hip_f16_s32, hip_bf16_s32  the product with the fp32 residual stream inside each Transformer2DModel (HipUNet(stream_f32=True): A/B)
+  hip_f16_fp8                BASELINE.json configs[4]: fp16 storage, every self-attention on e4m3 operands (HipUNet(attn_fp8=True),
+                             csrc/attention_f8.hip); e4m3 has 3 mantissa bits, so this leg carries its own measured bars
 
 The fp32 oracle is EXECUTED ON THE GPU by torch (rocBLAS fp32 GEMMs, torch's own im2col convolution -- MIOpen is switched off so a
 fresh box does not spend minutes in kernel search) so that 30-step, batch-2 and 192x128-latent comparisons take seconds instead of
@@ -75,8 +77,11 @@ def ref_policy():
         layers.sdpa = keep
 
 
-LEGS = {"hip_bf16": (torch.bfloat16, False), "hip_f16": (torch.float16, False),
-        "hip_bf16_s32": (torch.bfloat16, True), "hip_f16_s32": (torch.float16, True)}
+# leg -> (storage dtype, fp32 residual stream, self-attention on e4m3 operands)
+LEGS = {"hip_bf16": (torch.bfloat16, False, False), "hip_f16": (torch.float16, False, False),
+        "hip_bf16_s32": (torch.bfloat16, True, False), "hip_f16_s32": (torch.float16, True, False),
+        # BASELINE.json configs[4] ("fp16 + fp8 MFMA attention"; the pipeline call is /root/reference/inference_dc.py:550, same shapes as config 2)
+        "hip_f16_fp8": (torch.float16, False, True)}
 
 
 class World:
@@ -92,8 +97,8 @@ class World:
         eng0, cfgs, state = bench.build_engine(torch.bfloat16, dev, 0, 30, return_state=True, stream_f32=False)
         self.eng = {}
         for name in legs:
-            dt, s32 = LEGS[name]
-            self.eng[name] = eng0 if name == "hip_bf16" else bench.build_engine(dt, dev, 0, 30, state=state, stream_f32=s32)[0]
+            dt, s32, f8 = LEGS[name]
+            self.eng[name] = eng0 if name == "hip_bf16" else bench.build_engine(dt, dev, 0, 30, state=state, stream_f32=s32, attn_fp8=f8)[0]
         tcfg, gcfg, vcfg = cfgs
         as_o = lambda c, cls: cls(**{f.name: getattr(c, f.name) for f in dataclasses.fields(cls)})
 
@@ -302,8 +307,8 @@ def stage_vae(Wd, H, W, B=1):
     torch.cuda.synchronize()
     Wd.timing["oracle32_vae_s"] = time.time() - t0
     for leg, eng in Wd.eng.items():
-        if leg.endswith("_s32"):
-            continue                                          # the VAE has no transformer stream: same kernels as the default legs
+        if leg.endswith(("_s32", "_fp8")):
+            continue                                          # the VAE has no transformer stream / fp8 attention: same kernels as the default legs
         d = eng.vae.decode(z)
         Wd.put("cfg2_vae_decode", leg, rel=rel(d, dec32), rms=rms(d, dec32))
         e = eng.vae.encode_sample(img, nz)

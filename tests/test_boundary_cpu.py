@@ -139,6 +139,36 @@ def test_from_pretrained_round_trip(tmp_path):
     _round_trip(tmp_path)
 
 
+def test_memory_toggles_of_the_call_surface_exist_and_keep_the_model_intact(tmp_path):
+    """enable/disable_vae_slicing|tiling (/root/reference/src/tryon_pipeline.py:427-457), set_attention_slice, fuse/unfuse_qkv_projections,
+    set_default_attn_processor (src/unet_hacked_tryon.py:854-1004): a caller that toggles them must not hit AttributeError; they are
+    honest no-ops (already blockwise / already fused) that leave weights and processors usable."""
+    pipe = _round_trip(tmp_path)
+    pipe.enable_vae_slicing(); assert pipe.vae.use_slicing is True
+    pipe.disable_vae_slicing(); assert pipe.vae.use_slicing is False
+    pipe.enable_vae_tiling(); assert pipe.vae.use_tiling is True
+    pipe.disable_vae_tiling(); assert pipe.vae.use_tiling is False
+    t = pipe.unet
+    before = {k: v.clone() for k, v in t.state_dict().items()}
+    procs = dict(t.attn_processors)
+    for s in ("auto", "max", 4, [2, 2]):
+        t.set_attention_slice(s)
+    with pytest.raises(ValueError, match="slice_size"):
+        t.set_attention_slice("half")
+    t.fuse_qkv_projections()
+    assert t.original_attn_processors.keys() == procs.keys()
+    t.unfuse_qkv_projections()
+    assert all(t.attn_processors[k] is procs[k] for k in procs)
+    after = t.state_dict()
+    assert set(before) == set(after) and all(torch.equal(before[k], after[k]) for k in before)
+    with pytest.raises(NotImplementedError, match="FreeU"):
+        t.enable_freeu(0.9, 0.2, 1.2, 1.4)
+    t.disable_freeu()
+    g = pipe.unet_encoder
+    g.set_default_attn_processor()
+    assert all(type(p).__name__ == "AttnProcessor2_0" for p in g.attn_processors.values())
+
+
 def test_pipeline_argument_errors_and_no_cpu_path(tmp_path):
     pipe = _round_trip(tmp_path)
     B, H, W = 1, 128, 128

@@ -104,6 +104,13 @@ def test_fused_cross_attention_and_upsample_contracts_are_checked_on_the_host():
         with pytest.raises(RuntimeError, match=msg):
             ffi.call("idmvton_gemm_conv", a, 0)
     a = lin()
+    x = xa()                                                                 # the image-prompt segment holds one 32-key block: 33 keys must be refused,
+    x.nseg = 2                                                               # not silently truncated
+    x.k[1], x.vt[1], x.ldk[1], x.ldvt[1], x.nk[1], x.k_rows[1] = 0x70000, 0x80000, 128, 48, 33, 64
+    a.mode, a.xattn = ffi.EPI_XATTN, C.pointer(x)
+    with pytest.raises(RuntimeError, match=r"segment 1: nk=33 \(<= 32\)"):
+        ffi.call("idmvton_gemm_conv", a, 0)
+    a = lin()
     x = xa()
     a.mode, a.xattn, a.bias = ffi.EPI_XATTN, C.pointer(x), 0x60000           # nothing else may sit in that epilogue
     with pytest.raises(RuntimeError, match="nothing else in its epilogue"):
@@ -387,3 +394,33 @@ def test_bench_rank_logic_at_world_8_under_gloo(tmp_path):
     for (a0, a1), (b0, b1) in zip(first, first[1:]):
         assert b0 >= a1 - 2e-3, (a0, a1, b0, b1)
     assert time.time() - t0 < 300
+
+
+def test_feature_tokens_follow_the_topology_not_the_channel_count():
+    """block_out_channels may repeat a width ((64, 128, 128)): the resolution level of every transformer is recorded while the topology
+    is walked, so the real token count of each exported feature stays right (a {channels: level} map collapsed two levels)."""
+    import torch
+    from idm_vton_amd import config as pc
+    from idm_vton_amd.unet import HipUNet
+    cfg = pc.UNetConfig(mode="garmnet", in_channels=4, addition_embed_type=None, encoder_hid_dim_type=None, block_out_channels=(64, 128, 128),
+                        down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                        up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 1, 1),
+                        num_attention_heads=(1, 2, 2), cross_attention_dim=64, norm_num_groups=32)
+    u = HipUNet(cfg, {k: torch.zeros(s) for k, s in pc.unet_param_shapes(cfg)}, torch.bfloat16, "cpu")
+    # 10x10 latent -> levels 10x10, 5x5, 3x3: down 1 (x2) at 5x5, down 2 (x2) + mid + up 0 (x3) at 3x3, up 1 (x3) at 5x5
+    assert u.feature_tokens(10, 10) == [25, 25, 9, 9, 9, 9, 9, 9, 25, 25, 25]
+
+
+def test_gemm_conv_f8_refuses_what_the_c_contract_refuses():
+    """ops.gemm_conv(f8=...) used to clear IO_BIAS_F32 / IO_RES_F32 silently; now the Python side raises like the C check."""
+    import torch
+    from idm_vton_amd import ops
+    x = torch.zeros(64, 64, dtype=torch.bfloat16)
+    w = torch.zeros(64, 64, dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, dtype=torch.uint8)
+    with pytest.raises(ValueError, match="bias in the storage dtype"):
+        ops.gemm_conv([ops.SegSpec(x, 0, 64)], w, 64, out=out, bias=torch.zeros(64, dtype=torch.float32), f8=(1.0, 1.0))
+    with pytest.raises(ValueError, match="no residual"):
+        ops.gemm_conv([ops.SegSpec(x, 0, 64)], w, 64, out=out, res=x, f8=(1.0, 1.0))
+    with pytest.raises(ValueError, match="multiple of 64"):
+        ops.gemm_conv([ops.SegSpec(x, 0, 64)], w, 64, out=out[:, :0], vt=torch.zeros(2, 64, 32, dtype=torch.uint8), vt_n0=0, vt_tokens=32, f8=(1.0, 1.0))
