@@ -1,0 +1,15 @@
+// gemm_tiles_xattn.hip -- attn2.to_q with the cross-attention as its epilogue (xattn.cuh): plain Linear loader, ring pipeline.
+#include "gemm_body.cuh"
+
+template <typename T>
+static int run(const GemmParams& p, int bn, int bm, hipStream_t st) {
+    const dim3 grid(p.tiles_n * p.tiles_m);
+    if (bn == 128 && bm == 64) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 64, 2, 2, 3, 2>), grid, dim3(256), 0, st, p);
+    else if (bn == 128 && bm == 128) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 128, 2, 2, 3, 1>), grid, dim3(256), 0, st, p);
+    else if (bn == 128 && bm == 256) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 256, 2, 4, 3, 2>), grid, dim3(512), 0, st, p);
+    else return 1;
+    return 0;
+}
+int gemm_tiles_xattn(const GemmParams& p, bool bf16, int bn, int bm, hipStream_t st) {
+    return bf16 ? run<bf16_t>(p, bn, bm, st) : run<f16_t>(p, bn, bm, st);
+}

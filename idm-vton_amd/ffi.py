@@ -17,7 +17,7 @@ GN_X_F32, GN_Y_SPLIT, GN_AFFINE_F32 = 1, 2, 4
 LAYOUT_SPLIT, LAYOUT_NHWC_F32 = 1, 2
 SPLIT_ACT, SPLIT_W3, SPLIT_W3T = 0, 1, 2
 MAX_SEG = 24
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i32, u32, f32, vp = C.c_int32, C.c_uint32, C.c_float, C.c_void_p
 

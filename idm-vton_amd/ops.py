@@ -44,7 +44,8 @@ def _call(fn_name, args, flops=0.0, bytes_=0.0):
 # Per-shape kernel configuration table measured on an MI355X by tools/gpu_tune.py (every entry was checked there against the
 # default configuration's output on the real operands before it was admitted).  Missing file / missing key => the
 # library's built-in heuristic (tile_hint / tune = 0).
-TUNE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_gfx950.json")
+# IDMVTON_TUNE_TABLE=<file>: another tuning table than the committed one (A/B of two tables on one box; measurement only)
+TUNE_PATH = os.environ.get("IDMVTON_TUNE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_gfx950.json")
 _TUNE = {"gemm": {}, "attn": {}}
 RECORD = None          # tools/gpu_tune.py: list collecting (kind, key, args struct, keep-alive tensors) of every launch
 

@@ -93,8 +93,12 @@ typedef struct {
     void* vt; int32_t vt_n0; int32_t vt_tokens;
     int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
-                                    variant 1 with register-prefetched fragments on every tile; variant 3 = 256x256 as 4 waves of 128x128 (AGPR
-                                    accumulators, one wave per SIMD); variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
+                                    the 128x256 and 64x64 ring tiles with register-prefetched fragments; variant 6 = 8-wave forms of the tiles that
+                                    run one workgroup per CU: 128x128 (64x32 per wave) and 320x256 (N = 320 in one weight tile); variant 7 = 128x128
+                                    with INTRA-WORKGROUP SPLIT-K (two 4-wave groups contract alternate k-tiles, partial sums meet in LDS; low nibble
+                                    of the BM field: 1 = register-prefetched fragments) -- the only tile whose summation order differs from the
+                                    others (two partial sums), so its results match theirs to fp32 rounding, not bit for bit; variants 6 / 7 fall
+                                    back to the variant-1 tile for launches with a V^T part; variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
                                     of the BM field = placement form 0 | 1; bit 14 of it, tests only: 5 persistent workgroups) and 256x192 -- a PERSISTENT kernel:
                                     min(tiles, CUs) workgroups walk the tile raster.  Bit 15
                                     (0x8000) forces the 8-byte epilogue (measurement only; default: 16-byte accesses when every
