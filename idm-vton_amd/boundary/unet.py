@@ -236,11 +236,11 @@ class _UNetBase(nn.Module):
         key = (params_version(self), ip_scale)
         if key != self._hip_key:
             # engine options a drop-in user selects without touching the reference script: IDMVTON_ATTN_FP8=1 (BASELINE configs[4]: self-
-            # attention on e4m3 operands), IDMVTON_STREAM_F32=1 (fp32 residual stream inside each Transformer2DModel), IDMVTON_FUSE_LN=1
+            # attention on e4m3 operands), IDMVTON_STREAM_F32=1 (fp32 residual stream inside each Transformer2DModel)
             import os
             flag = lambda k: os.environ.get(k, "0") == "1"
             self._hip = HipUNet(self.cfg, self.state_dict(), p0.dtype, p0.device, stream_f32=flag("IDMVTON_STREAM_F32"),
-                                fuse_ln=flag("IDMVTON_FUSE_LN"), attn_fp8=flag("IDMVTON_ATTN_FP8"))
+                                attn_fp8=flag("IDMVTON_ATTN_FP8"))
             self._hip.ip_scale = ip_scale
             self._hip_key = key
         return self._hip

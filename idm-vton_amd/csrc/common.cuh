@@ -83,17 +83,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// 8-byte payload words of an in-launch hand-off between workgroups (guide G16): one aligned agent-scope access each, never plain --
-// the store is written through past this XCD's L2, the load does not hit stale lines of this CU's L1 / this XCD's L2.
-__device__ __forceinline__ void st_agent_f2(float* p, float x, float y) {
-    const unsigned long long bits = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
-    __hip_atomic_store((unsigned long long*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_agent_f2(const float* p) {
-    const unsigned long long bits = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)bits), __uint_as_float((unsigned)(bits >> 32)));
-}
-
 // Wave-wide sum on the DPP path (no LDS crossbar: __shfl_xor is ds_bpermute_b32, ~100 cycles a step): quad butterflies, row mirrors,
 // then the four 16-lane row totals through readlane.  The result is wave-uniform and the summation ORDER is fixed (deterministic).
 __device__ __forceinline__ float wave_sum_dpp(float v) {

@@ -9,7 +9,7 @@ int idmvton_set_error(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* idmvton_last_error(void) { return g_err; }
-extern "C" int idmvton_abi_version(void) { return 8; }   // 8: gemm_conv tile_hint variants 6 (8-wave 128x128, 320x256) and 7 (intra-workgroup split-K), variant 3 removed; 7: IDMVTON_IO_OUT_F8 (gemm_conv writes e4m3 q / k / V^T for idmvton_attn_f8); 6: split-precision VAE path (idmvton_split, GN / softmax / layout flags, IDMVTON_IO_BIAS_F32), IDMVTON_MAX_SEG 24
+extern "C" int idmvton_abi_version(void) { return 8; }   // 8: gemm_conv tile_hint variant 6 (8-wave 128x128, 320x256), variant 3 and the LayerNorm-fold fields (rowstats_*, ln_*) removed; 7: IDMVTON_IO_OUT_F8 (gemm_conv writes e4m3 q / k / V^T for idmvton_attn_f8); 6: split-precision VAE path (idmvton_split, GN / softmax / layout flags, IDMVTON_IO_BIAS_F32), IDMVTON_MAX_SEG 24
 
 // ---- TryonNet input: cat([latents]*2 | mask | masked | pose) -> NHWC[cpad] (tryon_pipeline.py:1769,1777) ----
 template <typename T>

@@ -4,20 +4,15 @@
 #pragma once
 #include <type_traits>
 #if !defined(__gfx950__) && !defined(__gfx942__) && defined(__HIP_DEVICE_COMPILE__)
-#error "gemm_body.cuh: the in-launch LayerNorm hand-off and the counted vmcnt pipeline are written for gfx94x/gfx950 (stores counted in vmcnt)"
+#error "gemm_body.cuh: the counted vmcnt pipeline is written for gfx94x/gfx950 (stores counted in vmcnt)"
 #endif
 #include "common.cuh"
 #include "gemm_common.cuh"
 
 // TR = this n-tile is written transposed (V^T epilogue): the MFMA operands are swapped so the accumulator is D[m][n].
 // Block = WN x WM waves; wave (wn, wm) owns the (BN/WN) x (BM/WM) sub-tile as NI x MI 32x32 MFMA tiles.
-// SK > 1 (intra-workgroup split-K; V1 ring only): the workgroup is SK groups of WN x WM waves, group g contracts the k-tiles t = g (mod SK) of the
-// SAME output tile through its own LDS ring (all groups cross the same workgroup barriers) and the partial accumulators meet in LDS at the end.  For
-// the launches whose output gives each CU only ONE 128x128 tile (M = 3072, N = 1280: 240 tiles) this puts two waves on every SIMD -- somebody to
-// cover the fragment-read / DMA / barrier waits of the 4-wave tile -- without a second tile's operand traffic and without any hand-off between
-// workgroups (the inter-workgroup split-K of round 4 lost its gain to the agent-scope hand-off).
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR, bool XA = false, int SK = 1>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, const int m0, const int n0) {
+template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, bool LIN, bool PF, bool TR, bool XA = false>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const int m0, const int n0) {
     typedef typename VT<T>::v8 v8;
     typedef typename VT<T>::v4 v4;
     constexpr int NW = WN * WM;
@@ -26,14 +21,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
     constexpr int WBYTES = BN * 128, XBYTES = BM * 128; // one LDS stage of each operand
     constexpr int WI = BN / (8 * NW), XI = BM / (8 * NW); // DMA instructions per wave per tile (8 rows each)
     static_assert(WI >= 1 && XI >= 1 && WI * 8 * NW == BN && XI * 8 * NW == BM, "tile / wave-count mismatch");
-    static_assert(SK == 1 || (V1 && !XA), "split-K groups exist for the ring pipeline, without the fused cross-attention");
-    const int lane = threadIdx.x & 63;
-    const int wave_wg = uniform(threadIdx.x >> 6);
-    const int grp = SK > 1 ? wave_wg / NW : 0;           // wave-uniform: this wave's split-K group
-    const int wave = SK > 1 ? wave_wg % NW : wave_wg;    // its index inside the group
-    char* smem = smem_wg + grp * (ST * (WBYTES + XBYTES));
     char* sW = smem;
     char* sX = smem + ST * WBYTES;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
     const int wn = wave / WM, wm = wave % WM;
     const int u = lane >> 5, l31 = lane & 31;
 
@@ -49,7 +41,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
     int x_pix[XI], x_oy[XI], x_ox[XI], x_c8[XI];
     uint32_t x_off[XI];                                  // LIN only
     const int HoWo = p.Ho * p.Wo;
-    auto kbyte = [&](int t) -> uint32_t { return (uint32_t)(t * SK + grp) * 128u; };   // t counts the group's own tiles: its k-tiles are t*SK + grp
+    auto kbyte = [&](int t) -> uint32_t { return (uint32_t)t * 128u; };
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int R = (wave * XI + i) * 8 + lrow;
@@ -73,14 +65,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
     const int hin = p.ups ? p.Ho : p.Hi, win = p.ups ? p.Wo : p.Wi;
 
     int si = 0, kseg = 0;                                // K-segment cursor of the NEXT tile to issue
-    auto advance = [&](int steps) {                      // move the cursor `steps` k-tiles on (segment lengths are multiples of 64)
-#pragma unroll
-        for (int a = 0; a < steps; ++a) {
-            kseg += 64;
-            if (kseg >= p.seg[si].len) { kseg = 0; ++si; }
-        }
-    };
-    if constexpr (SK > 1 && !LIN) advance(grp);
     auto issue = [&](int t, int buf) {
         char* dW = sW + buf * WBYTES + wave * (WI * 1024);
         char* dX = sX + buf * XBYTES + wave * (XI * 1024);
@@ -101,10 +85,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
                 const uint32_t off = ((uint32_t)(x_pix[i] + iy * p.Wi + ix) * (uint32_t)sg.pitch + sg.coff + kseg + x_c8[i]) * 2u;
                 dma16(rs_x, dX + i * 1024, ok ? off : OOB_SENTINEL);
             }
-            if constexpr (SK == 1) {
-                kseg += 64;
-                if (kseg >= sg.len) { kseg = 0; ++si; }
-            } else advance(SK);
+            kseg += 64;
+            if (kseg >= sg.len) { kseg = 0; ++si; }
         }
     };
 
@@ -138,9 +120,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
             }
         }
         if constexpr (!LIN) {
-            if constexpr (SK == 1) {
-                if (s == 3) { kseg += 64; if (kseg >= sgc.len) { kseg = 0; ++si; } }
-            } else if (s == 3) advance(SK);
+            if (s == 3) { kseg += 64; if (kseg >= sgc.len) { kseg = 0; ++si; } }
         }
     };
 
@@ -211,12 +191,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
         }
     };
 
-    // folded LayerNorm: this thread's row of the tile, (rstd, -rstd*mean) as its producer's last tile left it; one 8-byte load in
-    // flight under the whole main loop (the per-tile fold of 20-40 partials this replaces cost 5-17 us per consumer launch)
-    static_assert(NW * 64 >= BM, "one thread per tile row");
-    float2 ln_ab = make_float2(1.f, 0.f);
-    if (p.ln_rowstats && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) ln_ab = ((const float2*)p.ln_rowstats)[m0 + threadIdx.x];
-
     // fused cross-attention (xattn.cuh): this wave's head and batch element; its K fragments travel under the main loop
     v8 xkf[XA ? XA_NK : 1];
     int xa_b = 0, xa_h = 0;
@@ -227,8 +201,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
         xa_h = (n0 + wn * SN) >> 6;
         xattn_load_k<T>(p.xa, xa_b, xa_h, lane, xkf);
     }
-    const int nt_all = p.Ktot >> 6;
-    const int nt = SK > 1 ? (nt_all - grp + SK - 1) / SK : nt_all;      // this group's k-tiles
+    const int nt = p.Ktot >> 6;
     if constexpr (!V1) {
         issue(0, 0);
         for (int t = 0; t < nt; ++t) {
@@ -244,125 +217,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem_wg, co
         for (int s = 0; s < ST - 1; ++s)
             if (s < nt) issue(s, s);
         int cbuf = 0, ibuf = ST - 1;                     // buffer computed this iteration / buffer refilled this iteration
-        const int nloop = SK > 1 ? (nt_all + SK - 1) / SK : nt;          // every group crosses the same number of workgroup barriers
-        for (int t = 0; t < nloop; ++t) {
+        for (int t = 0; t < nt; ++t) {
             // tiles t .. t+ST-2 are outstanding (fewer at the tail); only tile t has to have landed
             if (t + ST - 2 < nt) wait_vmcnt<(ST - 2) * LPT>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                // every wave's share of tile t landed; all are done with tile t-1
             asm volatile("" ::: "memory");
-            if (SK == 1 || t < nt)                       // (wave-uniform) a group with one k-tile fewer only keeps the barrier count
-                compute(cbuf, t + ST - 1 < nt, t + ST - 1, ibuf);    // tile t+ST-1's DMA is issued in four parts between the k-steps
+            compute(cbuf, t + ST - 1 < nt, t + ST - 1, ibuf);    // tile t+ST-1's DMA is issued in four parts between the k-steps
             cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
             ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
         }
     }
 
-    if constexpr (SK == 2) {
-        // ---- the two groups' partial sums meet in LDS; then each group finishes HALF of its waves' sub-tile (32-row block mi = g of every wave
-        // position), so the store-issue-bound epilogue is shared by all 8 waves.  Exchange area: [wave position][ni][quarter][lane] x 16 bytes,
-        // lane-contiguous 16-byte accesses (conflict-free); group g publishes its accumulators of the OTHER group's half into that group's ring. ----
-        static_assert(MI == 2 && !TR && NW * NI * 4096 <= ST * (WBYTES + XBYTES), "split-K exchange: 64-row wave tiles, the exchange fits one group's ring");
-        __builtin_amdgcn_s_barrier();                    // every wave of both groups is done reading the operand stages
-        asm volatile("" ::: "memory");
-        // (the group index picks accumulator registers, so each group runs its own copy of the code: a runtime index would move them to scratch)
-        auto finish = [&](auto gc) {
-            constexpr int G = decltype(gc)::value;
-            char* xch = smem_wg + (1 - G) * (ST * (WBYTES + XBYTES)) + (wave * NI) * 4096 + lane * 16;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x16& a = acc[ni][1 - G];
-                    *(float4*)(xch + ni * 4096 + q * 1024) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-                }
-            __syncthreads();
-            f32x16 half[NI][1];
-            const char* mine = smem_wg + G * (ST * (WBYTES + XBYTES)) + (wave * NI) * 4096 + lane * 16;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 o = *(const float4*)(mine + ni * 4096 + q * 1024);
-                    const f32x16& a = acc[ni][G];
-                    // group 0's partial first, group 1's second, whichever group adds: the sum is the same in both halves of the tile
-                    half[ni][0][4 * q] = G == 0 ? a[4 * q] + o.x : o.x + a[4 * q];
-                    half[ni][0][4 * q + 1] = G == 0 ? a[4 * q + 1] + o.y : o.y + a[4 * q + 1];
-                    half[ni][0][4 * q + 2] = G == 0 ? a[4 * q + 2] + o.z : o.z + a[4 * q + 2];
-                    half[ni][0][4 * q + 3] = G == 0 ? a[4 * q + 3] + o.w : o.w + a[4 * q + 3];
-                }
-            // rows of this half: m0 + wm*SM + G*32 + l31 = m0 + (2 wm + G) * 32 + l31
-            gemm_epilogue<T, NI, 1, SN, 32, false>(p, half, m0, n0, wn, 2 * wm + G, lane, nullptr);
-        };
-        if (grp == 0) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 1>{});
-        return;
-    }
-
-    const float* fin = nullptr;                          // LDS: (rstd, -rstd*mean) of this tile's rows, nullptr = no folded LayerNorm
-    if (p.ln_rowstats) {                                 // block-uniform: LayerNorm of the activation operand folded into this GEMM
-        __syncthreads();                                 // every wave is done with the last LDS stage
-        if ((int)threadIdx.x < BM) ((float2*)smem)[threadIdx.x] = ln_ab;
-        __syncthreads();
-        fin = (const float*)smem;
-    }
     if constexpr (XA) {                                  // the accumulators are q of one head per wave: replace them by the cross-attention output
         v8 xvf[XA_NV];
         xattn_load_v<T>(p.xa, xa_b, xa_h, lane, xvf);
         xattn_compute<T, MI>(p.xa, p.M, acc, m0 + wm * SM, lane, xkf, xvf);
     }
-    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, fin);
-
-    if (p.rs_counter) {                                  // block-uniform: producer of LayerNorm row statistics
-        // Inter-workgroup hand-off inside the launch (guide G16, "payload write-through + counter"): the partials left as agent-scope
-        // stores; every wave drains them, one lane counts this tile on its row tile; the tile that arrives last reads the row tile's
-        // partials back with agent-scope loads (never plain ones: this CU's L1 / this XCD's L2 may hold older lines of the same
-        // addresses), folds them in a fixed order and leaves the counter zero for the next launch.
-        constexpr int NT = NW * 64, TPR = NT / BM;       // threads per row
-        static_assert(TPR >= 1 && TPR * BM == NT, "threads per row");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                 // also: every wave is done with `fin`
-        unsigned* flag = (unsigned*)smem;
-        const int tid = threadIdx.x;
-        uint32_t* cnt = p.rs_counter + m0 / BM;
-        if (tid == 0) {
-            // acq_rel at agent scope: a release for this tile's partials (already written through and drained above; the fence makes
-            // that a property of the memory model instead of the gfx9 vmcnt counting stores) and an acquire for the last arriver
-            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = old + 1u == (unsigned)p.tiles_n ? 1u : 0u;
-        }
-        __syncthreads();
-        if (*flag) {
-            float* scr = (float*)(smem + 16);            // [TPR][BM][2] partial folds
-            const int r = tid % BM, part = tid / BM;
-            const int P = p.rs_parts, chunk = (P + TPR - 1) / TPR;
-            const int m = m0 + r;
-            float s1 = 0.f, s2 = 0.f;
-            if (m < p.M) {
-                const float* rs = p.rowstats_out + (size_t)m * P * 2;
-                const int j1 = (part + 1) * chunk < P ? (part + 1) * chunk : P;
-                for (int j = part * chunk; j < j1; j += 8) {   // eight loads in flight per batch, summed in index order
-                    float2 t[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) t[q] = j + q < j1 ? ld_agent_f2(rs + (j + q) * 2) : make_float2(0.f, 0.f);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { s1 += t[q].x; s2 += t[q].y; }
-                }
-            }
-            scr[(part * BM + r) * 2] = s1; scr[(part * BM + r) * 2 + 1] = s2;
-            __syncthreads();
-            if (tid < BM && m0 + tid < p.M) {
-                double a1 = 0.0, a2 = 0.0;                    // E[x^2] - mean^2 cancels in fp32 on rows with a large mean: fold in double
-#pragma unroll
-                for (int q = 0; q < TPR; ++q) { a1 += (double)scr[(q * BM + tid) * 2]; a2 += (double)scr[(q * BM + tid) * 2 + 1]; }
-                const double invc = 1.0 / (double)(P * 32);
-                const double mean = a1 * invc;
-                double var = a2 * invc - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                const float rstd = (float)(1.0 / sqrt(var + (double)p.rs_eps));
-                *(float2*)(p.rs_final + (size_t)(m0 + tid) * 2) = make_float2(rstd, (float)(-(double)rstd * mean));   // read by the NEXT launch: plain store
-            }
-            if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane);
 }
 
 // Tile configurations.  id = the `variant` field of tile_hint (bits 28..31); BN/BM in bits 16..27 / 0..15.
@@ -435,25 +306,10 @@ static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
 }
 
 
-// Split-K form of the ring tile (gemm_body SK = 2): 2 x (WN x WM) waves, two LDS rings.
-template <typename T, int BN, int BM, int WN, int WM, int ST, bool LIN, bool PF>
-__global__ __launch_bounds__(2 * WN * WM * 64, 2) void gemm_sk_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * ST * (BN + BM) * 128];
-    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    constexpr int GM = 1024 / BM;
-    const int width = GM * p.tiles_n;
-    const int grp = wg / width, rem = wg - grp * width;
-    const int first = grp * GM;
-    const int gsz = p.tiles_m - first < GM ? p.tiles_m - first : GM;
-    const int tn = rem / gsz, tm = first + (rem - tn * gsz);
-    gemm_body<T, BN, BM, WN, WM, ST, true, LIN, PF, false, false, 2>(p, smem, tm * BM, tn * BN);
-}
-
 // Tile families, one translation unit each (gemm_tiles_*.hip).  Return 0 after launching, 1 when the family has no bn x bm tile.
 int gemm_tiles_v0(const GemmParams& p, bool bf16, int bn, int bm, bool lin, hipStream_t st);       // 2-stage 4-wave tiles 128x128, 128x64, 64x64
 int gemm_tiles_v1(const GemmParams& p, bool bf16, int bn, int bm, bool lin, hipStream_t st);       // LDS-ring tiles 256x256, 128x256, 128x128, 128x64, 64x64
 int gemm_tiles_v2(const GemmParams& p, bool bf16, int bn, int bm, bool lin, hipStream_t st);       // ring tiles with register-prefetched fragments: 128x256, 64x64
-int gemm_tiles_w8(const GemmParams& p, bool bf16, int bn, int bm, bool lin, hipStream_t st);       // 8-wave 128x128 (64x32 per wave) and 320x256
-int gemm_tiles_sk(const GemmParams& p, bool bf16, int bn, int bm, int pf, bool lin, hipStream_t st);   // 128x128 with intra-workgroup split-K
-int gemm_tiles_xattn(const GemmParams& p, bool bf16, int bn, int bm, hipStream_t st);              // attn2.to_q + fused cross-attention
+int gemm_tiles_w8(const GemmParams& p, bool bf16, int bn, int bm, int form, bool lin, hipStream_t st);   // 8-wave 128x128 (3 forms), 320x256; 16-wave 256x256, 128x256
+int gemm_tiles_xattn(const GemmParams& p, bool bf16, int bn, int bm, int w8, hipStream_t st);      // attn2.to_q + fused cross-attention (w8: 8-wave 128x128)
 int launch_gemm_lin(const GemmParams& p, bool bf16, int bm, int form, int grid_cap, hipStream_t st);   // gemm_lin.hip (variant 5)

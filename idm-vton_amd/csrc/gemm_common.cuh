@@ -19,9 +19,6 @@ struct GemmParams {
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
     int bias32;                                          // bias holds fp32 (plain 16-byte epilogue only): the split-precision VAE path
     int out8; float o8_scale, vt8_scale;                 // IDMVTON_IO_OUT_F8: out / vt are e4m3 bytes (plain 16-byte epilogue; vt in attention_f8.hip's slot order)
-    float* rowstats_out; int rs_parts;                   // producer of LayerNorm row statistics (per row, per 32-column group) ...
-    float* rs_final; uint32_t* rs_counter; float rs_eps; // ... folded per row by the last-arriving tile of each row tile: (rstd, -rstd*mean)
-    const float* ln_rowstats; const float* ln_colvec;    // consumer: LayerNorm folded into this GEMM (ln_rowstats = a producer's rs_final)
     XAttnParams xa;                                      // mode IDMVTON_EPI_XATTN: cross-attention applied to the accumulators (xattn.cuh)
 };
 
@@ -43,26 +40,7 @@ __device__ __forceinline__ void swap_cols8(const f32x16& c, const int gp, float 
 // Epilogue shared by every main loop: acc[ni][mi] is the wave's (SN x SM) sub-tile as NI x MI 32x32 accumulators (TR: D[m][n]).
 template <typename T, int NI, int MI, int SN, int SM, bool TR>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[NI][MI], const int m0, const int n0, const int wn, const int wm,
-                                              const int lane, const float* fin) {
-    // Folded LayerNorm (fin != nullptr, block-uniform): every accumulator value a of row m, column n becomes
-    //     rstd[m] * a - rstd[m]*mean[m] * s[n] + c[n]        ((rstd, -rstd*mean) = fin[2*row_in_tile ..], s = ln_colvec, c = ln_colvec + N)
-    // right where it is consumed (8 / 4 values at a time, like the bias): a separate pass over the accumulators costs 30-90 extra
-    // registers (the loads get clustered) and spills the 256x256 tile.
-    const float* lcs = p.ln_colvec;
-    const float* lcc = p.ln_colvec + p.N;
-    auto ln8 = [&](float (&v)[8], const float2 ab, const int n) {
-        const float4 s0 = *(const float4*)(lcs + n), s1 = *(const float4*)(lcs + n + 4);
-        const float4 c0 = *(const float4*)(lcc + n), c1 = *(const float4*)(lcc + n + 4);
-        v[0] = fmaf(v[0], ab.x, fmaf(ab.y, s0.x, c0.x)); v[1] = fmaf(v[1], ab.x, fmaf(ab.y, s0.y, c0.y));
-        v[2] = fmaf(v[2], ab.x, fmaf(ab.y, s0.z, c0.z)); v[3] = fmaf(v[3], ab.x, fmaf(ab.y, s0.w, c0.w));
-        v[4] = fmaf(v[4], ab.x, fmaf(ab.y, s1.x, c1.x)); v[5] = fmaf(v[5], ab.x, fmaf(ab.y, s1.y, c1.y));
-        v[6] = fmaf(v[6], ab.x, fmaf(ab.y, s1.z, c1.z)); v[7] = fmaf(v[7], ab.x, fmaf(ab.y, s1.w, c1.w));
-    };
-    auto ln4 = [&](float (&v)[4], const float2 ab, const int n) {
-        const float4 s0 = *(const float4*)(lcs + n), c0 = *(const float4*)(lcc + n);
-        v[0] = fmaf(v[0], ab.x, fmaf(ab.y, s0.x, c0.x)); v[1] = fmaf(v[1], ab.x, fmaf(ab.y, s0.y, c0.y));
-        v[2] = fmaf(v[2], ab.x, fmaf(ab.y, s0.z, c0.z)); v[3] = fmaf(v[3], ab.x, fmaf(ab.y, s0.w, c0.w));
-    };
+                                              const int lane) {
     typedef typename VT<T>::v4 v4;
     typedef typename VT<T>::v8 v8;
     const int u = lane >> 5, l31 = lane & 31;
@@ -115,14 +93,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         const int b = m / p.vt_tokens;
                         const int tok = m - b * p.vt_tokens + 8 * u;
                         v8 o;
-                        if (fin) {                         // registers 8gp + j <-> rows 16gp + 4u + (j & 3) + 8 (j >> 2) of this 32-row tile
-                            const float sn = lcs[n], cn = lcc[n];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 16 * gp + 4 * u + (j & 3) + 8 * (j >> 2)) * 2);
-                                acc[ni][mi][8 * gp + j] = fmaf(acc[ni][mi][8 * gp + j], ab.x, fmaf(ab.y, sn, cn));
-                            }
-                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (T)(acc[ni][mi][8 * gp + j] + bv);
                         *(v8*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
@@ -150,14 +120,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     // half-wave contracts in one PV MFMA (QK^T accumulator rows 8g+4u..+3, g = 0,1) are 16 contiguous bytes of V^T
                     if (p.vt_perm) tok = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
                     v4 o;
-                    if (fin) {
-                        const float sn = lcs[n], cn = lcc[n];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float2 ab = *(const float2*)(fin + (wm * SM + mi * 32 + 8 * g + 4 * u + j) * 2);
-                            acc[ni][mi][4 * g + j] = fmaf(acc[ni][mi][4 * g + j], ab.x, fmaf(ab.y, sn, cn));
-                        }
-                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (T)(acc[ni][mi][4 * g + j] + bv);
                     *(v4*)(vt + ((size_t)(b * Cv + n - p.vt_n0) * p.vt_tokens + tok)) = o;
@@ -174,7 +136,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const int m = m0 + wm * SM + mi * 32 + l31;
             if (m >= p.M) continue;
             const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
-            const float2 ab = fin ? *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2) : make_float2(1.f, 0.f);
             if (p.mode == IDMVTON_EPI_GEGLU) {
                 if constexpr (NI % 2 == 0) {
 #pragma unroll
@@ -186,7 +147,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                             swap_cols8(acc[2 * pr + 1][mi], gp, gt);
                             const int nh = n0 + wn * SN + pr * 64 + 16 * gp + 8 * u;   // h rows; gate rows are nh + 32
                             if (nh + 32 >= p.N) continue;
-                            if (fin) { ln8(h, ab, nh); ln8(gt, ab, nh + 32); }
                             const int jo = ((n0 + wn * SN + pr * 64) >> 1) + 16 * gp + 8 * u;
                             if (bias) {
                                 const v8 bh = *(const v8*)(bias + nh), bg = *(const v8*)(bias + nh + 32);
@@ -203,14 +163,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                float rs1 = 0.f, rs2 = 0.f;                // LayerNorm row statistics of the values stored below (this lane: 16 of the 32 columns)
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     float v[8];
                     swap_cols8(acc[ni][mi], gp, v);
                     const int n = n0 + wn * SN + ni * 32 + 16 * gp + 8 * u;
                     if (n >= p.N) continue;
-                    if (fin) ln8(v, ab, n);
                     if (bias) {
                         if (p.bias32) {                    // block-uniform
                             const float4* bp = (const float4*)((const float*)p.bias + n);
@@ -268,17 +226,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
                         *(v8*)(out + (size_t)m * p.ldo + n) = o;
-                        if (p.rowstats_out) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) { const float f = (float)o[j]; rs1 += f; rs2 += f * f; }
-                        }
                     }
-                }
-                if (p.rowstats_out) {                      // block-uniform; N % 32 == 0, so the whole 32-column group is inside N
-                    rs1 = xhalf_sum(rs1); rs2 = xhalf_sum(rs2);    // lanes l and l + 32 hold the two column halves of the same row
-                    const int grp32 = (n0 + wn * SN + ni * 32) >> 5;
-                    // one aligned 8-byte agent-scope store (write-through): read back by another CU's workgroup inside this launch
-                    if (u == 0 && grp32 < p.rs_parts) st_agent_f2(p.rowstats_out + ((size_t)m * p.rs_parts + grp32) * 2, rs1, rs2);
                 }
             }
         }
@@ -292,7 +240,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const int m = m0 + wm * SM + mi * 32 + l31;
         if (m >= p.M) continue;
         const T* rb = rowbias ? rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
-        const float2 ab = fin ? *(const float2*)(fin + (wm * SM + mi * 32 + l31) * 2) : make_float2(1.f, 0.f);
         if (p.mode == IDMVTON_EPI_GEGLU) {
             if constexpr (NI % 2 == 0) {
 #pragma unroll
@@ -306,10 +253,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float h = acc[2 * pr][mi][4 * g + j], gt = acc[2 * pr + 1][mi][4 * g + j];
-                            if (fin) {
-                                h = fmaf(h, ab.x, fmaf(ab.y, lcs[nh + j], lcc[nh + j]));
-                                gt = fmaf(gt, ab.x, fmaf(ab.y, lcs[nh + 32 + j], lcc[nh + 32 + j]));
-                            }
                             if (bias) { h += (float)bias[nh + j]; gt += (float)bias[nh + 32 + j]; }
                             o[j] = (T)(h * gelu_erf(gt));
                         }
@@ -327,7 +270,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-                if (fin) ln4(v, ab, n);
                 if (bias) {
                     const v4 bb = *(const v4*)(bias + n);
 #pragma unroll

@@ -43,7 +43,7 @@ static int launch_gemm(const GemmParams& p0, bool bf16, int variant, int bn, int
             bm = 64;
             p.tiles_m = (p.M + bm - 1) / bm;
         }
-        if (gemm_tiles_xattn(p, bf16, bn, bm, st))
+        if (gemm_tiles_xattn(p, bf16, bn, bm, variant == 6 && bn == 128 && bm == 128, st))
             return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN runs on the 128x64, 128x128 and 128x256 tiles (got %dx%d)", bn, bm);
         CHECK_LAUNCH("gemm_conv");
         return IDMVTON_OK;
@@ -53,27 +53,27 @@ static int launch_gemm(const GemmParams& p0, bool bf16, int variant, int bn, int
     else if (variant == 2) rc = gemm_tiles_v2(p, bf16, bn, bm, lin, st);
     else if (variant == 5) {                             // hand-scheduled Linear loop; anything it does not cover runs on the 8-wave ring tile
         if (!(bn == 256 && (bm == 256 || bm == 192))) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant 5 is the 256x256 / 256x192 tile");
-        if (lin && !p.ln_rowstats && !p.rs_counter) rc = launch_gemm_lin(p, bf16, bm, form, grid_cap, st);
+        if (lin) rc = launch_gemm_lin(p, bf16, bm, form, grid_cap, st);
         else if (bm == 256) rc = gemm_tiles_v1(p, bf16, 256, 256, lin, st);
         else {                                           // 256x192 exists only hand-scheduled: the same launch on the 128x256 ring tile
             p.tiles_n = (p.N + 127) / 128; p.tiles_m = (p.M + 255) / 256;
             rc = gemm_tiles_v1(p, bf16, 128, 256, lin, st);
         }
-    } else if (variant == 6 || variant == 7) {
-        // variant 6: 8-wave forms of tiles that have one workgroup per CU -- 128x128 as 2 x 4 waves of 64x32 (two waves per SIMD on one shared k-tile) and
-        //            320x256 (N = 320 in ONE weight tile: the 128-column tiles compute 384 columns for it);
-        // variant 7: 128x128 with intra-workgroup split-K (two 4-wave groups on alternate k-tiles, low nibble of BM: 1 = register-prefetched fragments);
-        //            sums in a different order than the other tiles (two partial sums), so not bit-identical to them.
-        // Neither carries a V^T part, the LayerNorm fold or the e4m3 output of the 128x128-per-wave exit; such launches run on the plain ring tile.
-        const int pf = variant == 7 ? (bm & 15) : 0;
-        if (variant == 7) bm &= ~15;
+    } else if (variant == 6) {
+        // 8-wave forms of tiles that have one workgroup per CU: 128x128 as 2 x 4 waves of 64x32 (two waves per SIMD on one shared k-tile: somebody
+        // to cover the fragment-read / DMA / barrier waits of the 4-wave tile) and 320x256 (N = 320 in ONE weight tile: the 128-column tiles compute
+        // 384 columns for it).  No V^T part; the 10-accumulator 320-column wave tile only has the 16-byte epilogue and no GEGLU pairing
+        // (gemm_common.cuh).  Launches they cannot take run on the plain ring tile.
+        // (Measured with them and removed, profiles/r05_tune_report_v1_new_tiles.json: 128x128 with INTRA-WORKGROUP SPLIT-K -- two 4-wave groups
+        //  on alternate k-tiles, two LDS rings, partial sums exchanged through LDS -- 6-20 % SLOWER than the 4-wave ring tile on every shape.)
+        const int form6 = bm & 15;                       // low nibble of the BM field: form of the 128x128 tile (gemm_tiles_w8.hip)
+        bm &= ~15;
         p.tiles_m = (p.M + bm - 1) / bm;
-        // (the 10-accumulator 320-column wave tile only has the 16-byte epilogue and no GEGLU pairing: gemm_common.cuh)
-        if (p.vt || p.ln_rowstats || p.rs_counter || (bn == 320 && (!p.wide || p.out8 || p.mode == IDMVTON_EPI_GEGLU))) {
-            const int fbn = bn == 320 ? 128 : bn, fbm = bm;
+        if (p.vt || (bn == 320 && (!p.wide || p.out8 || p.mode == IDMVTON_EPI_GEGLU))) {
+            const int fbn = bn == 320 ? 128 : bn;
             p.tiles_n = (p.N + fbn - 1) / fbn;
-            rc = gemm_tiles_v1(p, bf16, fbn, fbm, lin, st);
-        } else rc = variant == 6 ? gemm_tiles_w8(p, bf16, bn, bm, lin, st) : gemm_tiles_sk(p, bf16, bn, bm, pf, lin, st);
+            rc = gemm_tiles_v1(p, bf16, fbn, bm, lin, st);
+        } else rc = gemm_tiles_w8(p, bf16, bn, bm, form6, lin, st);
     } else return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: unknown variant %d", variant);
     if (rc) return idmvton_set_error(IDMVTON_E_ARG, "gemm_conv: variant %d has no %dx%d tile", variant, bn, bm);
     CHECK_LAUNCH("gemm_conv");
@@ -125,7 +125,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     if (xattn) {
         const idmvton_xattn* x = a->xattn;
         CHECK_ARG(x != nullptr && (x->nseg == 1 || x->nseg == 2), IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN needs `xattn` with 1 or 2 key segments");
-        CHECK_ARG(a->N % 64 == 0 && !a->bias && !a->res && !a->rowbias && !a->vt && !a->colscale_n && !a->io_flags && !a->ln_rowstats && !a->rowstats_out &&
+        CHECK_ARG(a->N % 64 == 0 && !a->bias && !a->res && !a->rowbias && !a->vt && !a->colscale_n && !a->io_flags &&
                   a->nseg == 1 && a->Ho == 1 && a->Hi == 1 && a->Wo == a->M && a->Wi == a->M && a->out && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0,
                   IDMVTON_E_ARG, "gemm_conv: IDMVTON_EPI_XATTN is a plain Linear with N %% 64 == 0 and nothing else in its epilogue");
         CHECK_ARG(x->tokens > 0 && x->tokens % 32 == 0 && a->M % x->tokens == 0, IDMVTON_E_SHAPE, "gemm_conv: xattn.tokens=%d (rows per batch element, a multiple of 32 dividing M=%d)", x->tokens, a->M);
@@ -159,20 +159,6 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     int variant = 1, bn = 64, bm = 64;
     static const bool env_narrow = getenv("IDMVTON_EPILOGUE_8B") != nullptr;   // measurement only (A/B of the whole pipeline)
     if ((a->tile_hint & 0x8000) || env_narrow) p.wide = 0;                      // measurement only: force the 8-byte epilogue
-    p.rowstats_out = a->rowstats_out; p.rs_parts = a->N / 32;
-    p.rs_final = a->rowstats_final; p.rs_counter = a->rowstats_counter; p.rs_eps = a->rowstats_eps;
-    p.ln_rowstats = a->ln_rowstats; p.ln_colvec = a->ln_colvec;
-    if (a->rowstats_out || a->rowstats_final || a->rowstats_counter) {
-        CHECK_ARG(a->rowstats_out && a->rowstats_final && a->rowstats_counter && a->rowstats_eps > 0.f, IDMVTON_E_ARG,
-                  "gemm_conv: rowstats_out, rowstats_final, rowstats_counter and rowstats_eps > 0 come together");
-        CHECK_ARG(a->N % 32 == 0 && !geglu && !a->vt && a->out && p.wide && !(a->io_flags & IDMVTON_IO_OUT_F32) &&
-                  ((uintptr_t)a->rowstats_out & 7) == 0 && ((uintptr_t)a->rowstats_final & 7) == 0 && ((uintptr_t)a->rowstats_counter & 3) == 0,
-                  IDMVTON_E_ARG, "gemm_conv: rowstats_out needs N %% 32 == 0 (N=%d), the plain 16-byte epilogue, a 16-bit out", a->N);
-    }
-    if (a->ln_rowstats) {
-        CHECK_ARG(a->ln_colvec && a->nseg == 1 && ((uintptr_t)a->ln_rowstats & 7) == 0 && ((uintptr_t)a->ln_colvec & 15) == 0,
-                  IDMVTON_E_ARG, "gemm_conv: folded LayerNorm needs one K segment (nseg=%d) and ln_colvec", a->nseg);
-    } else CHECK_ARG(!a->ln_colvec, IDMVTON_E_ARG, "gemm_conv: ln_colvec without ln_rowstats");
     p.res32 = (a->io_flags & IDMVTON_IO_RES_F32) ? 1 : 0;
     p.out32 = (a->io_flags & IDMVTON_IO_OUT_F32) ? 1 : 0;
     p.bias32 = (a->io_flags & IDMVTON_IO_BIAS_F32) ? 1 : 0;
@@ -182,8 +168,8 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.out8 = (a->io_flags & IDMVTON_IO_OUT_F8) ? 1 : 0;
     p.o8_scale = a->f8_out_scale; p.vt8_scale = a->f8_vt_scale;
     if (p.out8) {
-        CHECK_ARG(a->io_flags == IDMVTON_IO_OUT_F8 && a->mode == IDMVTON_EPI_NONE && !a->res && !a->rowbias && !a->ln_rowstats && !a->rowstats_out && p.wide,
-                  IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_OUT_F8 needs the plain 16-byte epilogue (no activation / residual / rowbias / fp32 IO / LayerNorm fold)");
+        CHECK_ARG(a->io_flags == IDMVTON_IO_OUT_F8 && a->mode == IDMVTON_EPI_NONE && !a->res && !a->rowbias && p.wide,
+                  IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_OUT_F8 needs the plain 16-byte epilogue (no activation / residual / rowbias / fp32 IO)");
         CHECK_ARG((!a->out || a->f8_out_scale > 0.f) && (!a->vt || (a->f8_vt_scale > 0.f && a->vt_tokens % 64 == 0 && ((uintptr_t)a->vt & 15) == 0)),
                   IDMVTON_E_ARG, "gemm_conv: IDMVTON_IO_OUT_F8: scales > 0, vt_tokens %% 64 == 0 (got %d), 16-byte aligned vt", a->vt_tokens);
     }
@@ -216,7 +202,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
                      !a->ups && s0.dy == 0 && s0.dx == 0 && (uint64_t)a->M * s0.pitch * 2 < 0x80000000ull;
     // no hint and the heuristic chose the 256x256 tile for a plain Linear: the hand-scheduled loop (gemm_lin.hip) won on every such shape it
     // was measured on (profiles/r04_gemm_probe_*.log: +5..11 % over the compiler-scheduled tile)
-    if (!a->tile_hint && bn == 256 && bm == 256 && lin && !a->ln_rowstats && !a->rowstats_counter) { variant = 5; bm = 257; }
+    if (!a->tile_hint && bn == 256 && bm == 256 && lin) { variant = 5; bm = 257; }
     hipStream_t st = (hipStream_t)stream;
     return launch_gemm(p, a->dtype == IDMVTON_BF16, variant, bn, bm, lin, st);
 }

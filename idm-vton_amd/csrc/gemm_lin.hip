@@ -230,7 +230,7 @@ __device__ __forceinline__ void gemm_lin_persistent(const GemmParams& p, char* s
         mfma_range(1, 0, NMF);
         // the next tile's pieces have had this whole k-tile to land; waiting here (not after the stores below) keeps the stores out of the wait
         if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane, nullptr);
+        gemm_epilogue<T, NI, MI, SN, SM, TR>(p, acc, m0, n0, wn, wm, lane);
     };
 
     coords(idx, m0, n0);
@@ -257,8 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lin_kernel(const GemmParams p) {
 // Called by gemm_conv.hip's launch_gemm for tile_hint variant 5 (BN = 256, BM = 256 | 192); `form` (the low nibble of tile_hint's BM field) selects
 // the placement of the 256-row tile: 0 = DMA split over steps 0 / 1, 1 (the form the tuning table uses) = everything behind step 0.  Forms 2-4
 // of the first measurement (barrier after 0 / 4 MFMAs, static priority for the younger half of the workgroup) were within noise of form 1
-// (profiles/r04_gemm_probe_h5_forms_v1.log) and were removed.  Preconditions checked by the caller: plain Linear (one K segment, no gather), no
-// folded LayerNorm.  grid_cap > 0 (tests only) limits the persistent grid so that small shapes walk several tiles per workgroup.
+// (profiles/r04_gemm_probe_h5_forms_v1.log) and were removed.  Precondition checked by the caller: plain Linear (one K segment, no gather).  grid_cap > 0 (tests only) limits the persistent grid so that small shapes walk several tiles per workgroup.
 static int persistent_grid(int ntiles, int grid_cap) {
     static int cus = 0;
     if (!cus) {

@@ -36,8 +36,7 @@ class GemmConvArgs(C.Structure):
                 ("M", i32), ("Ho", i32), ("Wo", i32), ("Hi", i32), ("Wi", i32), ("stride", i32), ("ups", i32),
                 ("out", vp), ("ldo", i32), ("bias", vp), ("rowbias", vp), ("rowbias_ld", i32),
                 ("rows_per_group", i32), ("res", vp), ("ldr", i32), ("mode", i32), ("vt", vp), ("vt_n0", i32),
-                ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("io_flags", i32), ("rowstats_out", vp), ("rowstats_final", vp), ("rowstats_counter", vp), ("rowstats_eps", f32),
-                ("ln_rowstats", vp), ("ln_colvec", vp), ("xattn", C.POINTER(XAttn)),
+                ("vt_tokens", i32), ("tile_hint", i32), ("vt_perm", i32), ("io_flags", i32), ("xattn", C.POINTER(XAttn)),
                 ("colscale_n", i32), ("colscale", f32), ("f8_out_scale", f32), ("f8_vt_scale", f32)]
 
 

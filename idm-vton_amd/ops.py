@@ -89,15 +89,11 @@ class SegSpec:
 
 def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, out=None, ldo=None, bias=None,
               rowbias=None, rowbias_ld=0, rows_per_group=1, res=None, ldr=None, geglu=False, gelu=False, quick_gelu=False, vt=None,
-              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, rowstats_out=None, ln=None,
-              xattn=None, f8=None):
+              vt_n0=0, vt_tokens=0, vt_perm=True, colscale_n=0, colscale=1.0, tile_hint=0, out_f32=False, xattn=None, f8=None):
     """out[M][N] = epilogue(X . W^T); X assembled from `segs` (list of SegSpec); w: [N][Ktot] contiguous.
     f8 = (out_scale, vt_scale): `out` ([M][n_out] uint8) and `vt` ([B][N - vt_n0][vt_tokens] uint8, fp8 slot order) are written as e4m3
     operands of attention_f8 (IDMVTON_IO_OUT_F8): value * scale, saturating, one rounding from the fp32 accumulator.
     fp32 residual stream: a float32 `res` is read as fp32; out_f32=True (or a float32 `out`) writes fp32 (io_flags).
-    LayerNorm folded into the GEMMs around it: rowstats_out = a RowStats on the PRODUCER of a hidden state (its tiles emit (sum, sum of
-    squares) per 32-column group of the stored values, the last tile to finish a row tile folds them to (rstd, -rstd*mean) per row);
-    ln = (that RowStats, colvec fp32 [2][N] {s, c}) on the CONSUMER, whose weights carry gamma (see ln_fold_weights).
     xattn = dict(segs=[dict(k=, vt=, nk=, ldk=, ldvt=, k_rows=)] * (1 | 2), tokens=rows per batch element, ip_scale=): the GEMM is a
     cross-attention's query projection and its epilogue is the attention (include/idmvton_hip.h, IDMVTON_EPI_XATTN); w's rows in
     accumulator order (xattn_q_weight()).
@@ -159,16 +155,6 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
     a.vt, a.vt_n0, a.vt_tokens = _ptr(vt), vt_n0, vt_tokens
     a.vt_perm = int(bool(vt_perm)) if vt is not None else 0
     a.colscale_n, a.colscale = colscale_n, colscale
-    if rowstats_out is not None:
-        rs = rowstats_out
-        if rs.M < M or rs.C != N:
-            raise ValueError(f"RowStats({rs.M}, {rs.C}) on a producer of [{M}][{N}]")
-        a.rowstats_out, a.rowstats_final, a.rowstats_counter, a.rowstats_eps = _ptr(rs.partials), _ptr(rs.final), _ptr(rs.counter), rs.eps
-    if ln is not None:
-        rs, colvec = ln
-        if rs.M < M or rs.C != Ktot:
-            raise ValueError(f"RowStats({rs.M}, {rs.C}) on a consumer of [{M}][{Ktot}]")
-        a.ln_rowstats, a.ln_colvec = _ptr(rs.final), _ptr(colvec)
     a.tile_hint = tile_hint if tile_hint else _TUNE["gemm"].get(gemm_key(a), 0)
     if RECORD is not None:
         RECORD.append(("gemm", gemm_key(a), type(a).from_buffer_copy(a), (segs, w, out, bias, rowbias, res, vt, xa, xattn)))
@@ -187,28 +173,6 @@ def xattn_q_weight(w):
     """attn2.to_q weight [heads*64][K] -> rows in the ACCUMULATOR ORDER the fused cross-attention epilogue contracts in: inside every group of
     16 output channels, bits 2 and 3 of the channel index swapped (the same involution as key_order_index)."""
     return w.index_select(0, key_order_index(w.shape[0], w.device)).contiguous()
-
-
-class RowStats:
-    """Scratch of one LayerNorm fold (include/idmvton_hip.h, rowstats_*): fp32 partials [M][C/32][2], final [M][2] = (rstd, -rstd*mean),
-    one uint32 arrival counter per 64 rows -- zero here, left zero by every launch.  One object serves every producer -> consumer pair
-    of its shape that runs on ONE stream in order; launches that may overlap need their own."""
-
-    def __init__(self, M, C, device, eps=1e-5):
-        if C % 32:
-            raise ValueError("RowStats: C %% 32 != 0 (C=%d)" % C)
-        self.M, self.C, self.eps = M, C, float(eps)
-        self.partials = torch.empty(M * (C // 32) * 2, dtype=torch.float32, device=device)
-        self.final = torch.empty(M * 2, dtype=torch.float32, device=device)
-        self.counter = torch.zeros((M + 63) // 64, dtype=torch.int32, device=device)
-
-
-def ln_fold_weights(w, gamma, beta):
-    """LayerNorm folded into the Linear that consumes it: LN(x) W^T = rstd*(x (gamma*W)^T) - rstd*mean*s + c.  Returns
-    (gamma-scaled weights in w's dtype, colvec fp32 [2][N] = {s[n] = sum_k of the STORED scaled weights, c[n] = sum_k beta[k] W[n][k]})."""
-    wf = w.float()
-    ws = (wf * gamma.float()[None, :]).to(w.dtype).contiguous()
-    return ws, torch.stack([ws.float().sum(1), wf @ beta.float()]).contiguous()
 
 
 def key_order_index(n, device=None):

@@ -48,8 +48,7 @@ class _Conv:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, fuse_ln=False, attn_fp8=False,
-                 fuse_xattn=True):
+    def __init__(self, cfg: UNetConfig, state_dict, dtype=torch.bfloat16, device="cuda", stream_f32=False, attn_fp8=False, fuse_xattn=True):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         # stream_f32: inside a Transformer2DModel the block-to-block hidden state (three `+ hidden_states` per block,
         # attentionhacked_tryon.py:348,384,412) stays fp32 from proj_in to the last block's ff.net.2, whose output is rounded once
@@ -57,17 +56,9 @@ class HipUNet:
         # measured at full size the option lowers the latent error by 10-35 % for 2.4 % of throughput --
         # operand rounding inside the branches, not the stream, is what bf16 storage costs.
         self.stream_f32 = bool(stream_f32)
-        # fuse_ln: norm1 / norm2 / norm3 of every BasicTransformerBlock folded into the GEMMs on either side (gemm_conv rowstats_out /
-        # ln_*): the to_out / ff.net.2 / proj_in epilogue emits the row statistics of the hidden state it writes, the to_q|k|v /
-        # attn2.to_q / GEGLU projection runs on the raw hidden state with gamma folded into its weights.  210 LayerNorm launches per
-        # TryonNet forward disappear (GarmentNet keeps norm1: its output is the exported feature).  Needs the 16-bit stream.
-        # OFF by default -- measured twice.  Per-consumer-tile fold of the partials (profiles/r03_lnfold_probe.log): QKV +12 us, GEGLU
-        # +16.5 us per launch, 1.45 vs 1.50 images/s.  One fold per row by the producer's last-arriving tile (the form kept, C ABI v5;
-        # profiles/r03_lnfold_final_stats_probe.log): consumers +2..+20 us of epilogue arithmetic, producers +5..+11 us for the
-        # in-launch hand-off (a returning device-scope atomic per tile), against ~8-10 us per LayerNorm launch removed: 1.465 vs
-        # 1.455 / 1.505.  Results are identical in tolerance either way (tests/kernel_checks.py::check_ln_fold).
-        self.fuse_ln = bool(fuse_ln) and not self.stream_f32
-        self._rowstats = {}
+        # (LayerNorm folded into the neighbouring GEMMs -- row statistics emitted by the producer's epilogue, gamma folded into the consumer's
+        #  weights -- was built and measured in rounds 3 and 4 in two forms, +-0 .. -3 % end to end, and removed in
+        #  round 5: norm1 / norm2 / norm3 run as LayerNorm kernels.)
         # attn_fp8 (BASELINE.json configs[4]: "fp16 + fp8 MFMA attention"): every self-attention (attn1) runs on e4m3 operands through
         # the block-scaled MFMA (csrc/attention_f8.hip); q, k, v are quantised with power-of-two scales 2^eq, 2^ek, 2^ev right after the
         # QKV projection.  Cross-attention (93 keys) and everything else stay 16-bit.  6e-2 .. 1e-1 max-rel per attention output (e4m3: 3 mantissa bits).
@@ -118,12 +109,6 @@ class HipUNet:
                 if self.tryon:
                     d["kv_ip"] = torch.cat([sd[f"{b}.attn2.processor.to_k_ip.weight"], sd[f"{b}.attn2.processor.to_v_ip.weight"]]).contiguous()
                 d["ff1_w"], d["ff1_b"] = interleave_geglu(sd[f"{b}.ff.net.0.proj.weight"], sd[f"{b}.ff.net.0.proj.bias"])
-                if self.fuse_ln:
-                    if self.tryon:                            # GarmentNet materialises norm1 (the exported feature): its QKV stays plain
-                        d["kv_plain"] = d["qkv"][ch:].clone()   # the garment features are already normalised: unscaled to_k | to_v
-                        d["qkv"], d["qkv_cv"] = ops.ln_fold_weights(d["qkv"], sd[f"{b}.norm1.weight"], sd[f"{b}.norm1.bias"])
-                    d["q2_w"], d["q2_cv"] = ops.ln_fold_weights(sd[f"{b}.attn2.to_q.weight"], sd[f"{b}.norm2.weight"], sd[f"{b}.norm2.bias"])
-                    d["ff1_w"], d["ff1_cv"] = ops.ln_fold_weights(d["ff1_w"], sd[f"{b}.norm3.weight"], sd[f"{b}.norm3.bias"])
                 d["p"] = b
                 blocks.append(d)
             self.tf[p] = dict(blocks=blocks, ch=ch, heads=heads, level=level)
@@ -257,29 +242,24 @@ class HipUNet:
         M = B * N
         nk = N if nk is None else nk
         feat = None
-        fuse = self.fuse_ln
-        rs = self._rowstats_buf(M, C) if fuse else None          # row statistics of the current hidden state (written by its producer)
         if not self.tryon:                                       # exported norm1 output (garmnet :321-322)
             fb = garment.get("feats_buf") if garment else None
             feat = fb[len(feats_out)][:B].view(M, C) if fb is not None else torch.empty(M, C, dtype=dt, device=dev)
         # attn_fp8: the projections write the e4m3 operands themselves (IDMVTON_IO_OUT_F8: one rounding, no quant launches) when the token
         # rows are whole 64-key tiles; other sizes project in 16 bits and quantise with idmvton_quant_f8
-        f8 = self._f8_fused(N) and not (fuse and self.tryon)
+        f8 = self._f8_fused(N)
         eq, ek, ev = self.f8_exp
         f8kw = dict(f8=(2.0 ** ek, 2.0 ** ev)) if f8 else {}
         qk = torch.empty(M, 2 * C, dtype=torch.uint8 if f8 else dt, device=dev)
         vt = torch.empty(B, C, N, dtype=torch.uint8 if f8 else dt, device=dev)
         qcs = ops.QSCALE * (2.0 ** (eq - ek) if f8 else 1.0)     # q columns: softmax scale (and 2^eq over the 2^ek every `out` column gets)
         # q columns leave the GEMM multiplied by softmax_scale * log2(e) (fp32, before the one rounding to the storage dtype)
-        if fuse and self.tryon:                                  # norm1 folded into the QKV projection
-            ops.linear(hs, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=ops.QSCALE, ln=(rs, blk["qkv_cv"]))
-        else:
-            n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
-            if feat is not None:
-                feats_out.append(feat.view(B, N, C))
-                if stop is not None and len(feats_out) >= stop:
-                    return None                          # GarmentNet: everything after the last export is dead compute
-            ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=qcs, **f8kw)
+        n1 = ops.layernorm(hs, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, out2=feat)
+        if feat is not None:
+            feats_out.append(feat.view(B, N, C))
+            if stop is not None and len(feats_out) >= stop:
+                return None                              # GarmentNet: everything after the last export is dead compute
+        ops.linear(n1, blk["qkv"], out=qk, vt=vt, vt_n0=2 * C, vt_tokens=N, colscale_n=C, colscale=qcs, **f8kw)
         segs = [dict(k=qk[:, C:], vt=vt, nk=nk, ldk=2 * C, ldvt=N, k_rows=N)]
         if self.tryon:
             if garment.get("kv") is not None:                   # K / V^T of the garment tokens projected ahead of time
@@ -294,7 +274,7 @@ class HipUNet:
                     g = gp
                 kg = torch.empty(Bg * N, C, dtype=torch.uint8 if f8 else dt, device=dev)
                 vtg = torch.empty(Bg, C, N, dtype=torch.uint8 if f8 else dt, device=dev)
-                ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N, **f8kw)
+                ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N, **f8kw)
             garment["idx"] += 1
             segs.append(dict(k=kg, vt=vtg, nk=nk, ldk=C, ldvt=N, k_rows=N, b0=B - Bg))
         att = torch.empty(M, C, dtype=dt, device=dev)
@@ -316,14 +296,14 @@ class HipUNet:
         else:
             ops.attention(qk, att, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C, q_prescaled=True)
         f32 = hs.dtype == torch.float32                          # the fp32 residual stream (see __init__)
-        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
+        hs = ops.linear(att, sd[p + ".attn1.to_out.0.weight"], bias=sd[p + ".attn1.to_out.0.bias"], res=hs, out_f32=f32)
         # cross attention
         kv = ctx["kv"][p]
         seg_t = dict(k=kv["kt"], vt=kv["vtt"], nk=ctx["nt"], ldk=C, ldvt=ctx["rt"], k_rows=ctx["rt"])
         xsegs = [seg_t] + ([dict(k=kv["ki"], vt=kv["vti"], nk=ctx["ni"], ldk=C, ldvt=ctx["ri"], k_rows=ctx["ri"])] if self.tryon else [])
         # (not for the timestep-batched GarmentNet at the 1280-channel level: at M = 9216 the plain projection runs on the 256x256 tile at twice
         #  the rate of the 128-column tiles the fused form needs -- 55 us for the two launches against 60 fused, profiles/r04_xattn_probe_*.log)
-        if self.fuse_xattn and not fuse and N % 32 == 0 and not (C >= 1280 and M >= 8192) and \
+        if self.fuse_xattn and N % 32 == 0 and not (C >= 1280 and M >= 8192) and \
                 all(sg["nk"] <= (96, 32)[i] and sg["k_rows"] >= (sg["nk"] + 31) // 32 * 32 for i, sg in enumerate(xsegs)):
             # (96 text keys / 32 image-prompt keys are what the fused epilogue holds; a larger segment takes the two-launch path below)
             # attn2.to_q with the cross-attention as its epilogue (csrc/xattn.cuh): q never leaves the registers, no attention launch
@@ -332,35 +312,19 @@ class HipUNet:
             n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
             att2 = ops.linear(n2, blk["q2_xw"], xattn=dict(segs=xsegs, tokens=N, ip_scale=self.ip_scale))
         else:
-            if fuse:                                             # norm2 folded into attn2.to_q
-                q2 = ops.linear(hs, blk["q2_w"], ln=(rs, blk["q2_cv"]))
-            else:
-                n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
-                q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
+            n2 = ops.layernorm(hs, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+            q2 = ops.linear(n2, sd[p + ".attn2.to_q.weight"])
             att2 = torch.empty(M, C, dtype=dt, device=dev)
             if self.tryon:
                 ops.attention(q2, att2, xsegs, heads, mode=ffi.ATTN_CROSS, ip_scale=self.ip_scale, B=B, Nq=N, ldq=C, ldo=C)
             else:
                 ops.attention(q2, att2, xsegs, heads, B=B, Nq=N, ldq=C, ldo=C)
-        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32, rowstats_out=rs)
+        hs = ops.linear(att2, sd[p + ".attn2.to_out.0.weight"], bias=sd[p + ".attn2.to_out.0.bias"], res=hs, out_f32=f32)
         # feed-forward (GEGLU fused into the first GEMM's epilogue)
-        if fuse:                                                 # norm3 folded into the GEGLU projection
-            gg = ops.linear(hs, blk["ff1_w"], bias=blk["ff1_b"], geglu=True, ln=(rs, blk["ff1_cv"]))
-        else:
-            n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
-            gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
-        # the next block's norm1 reads this output's row statistics (TryonNet; GarmentNet runs norm1 as a kernel: it is the exported feature)
-        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs, out_f32=f32 and not last,
-                        rowstats_out=rs if (fuse and self.tryon and not last) else None)
+        n3 = ops.layernorm(hs, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
+        gg = ops.linear(n3, blk["ff1_w"], bias=blk["ff1_b"], geglu=True)
+        hs = ops.linear(gg, sd[p + ".ff.net.2.weight"], bias=sd[p + ".ff.net.2.bias"], res=hs, out_f32=f32 and not last)
         return hs
-
-    def _rowstats_buf(self, M, C):
-        """Scratch of the LayerNorm fold (ops.RowStats: producer GEMM -> consumer GEMM), one per shape: this UNet's launches are
-        ordered on one stream, and the other UNet of the pipeline has its own."""
-        key = (M, C)
-        if key not in self._rowstats:
-            self._rowstats[key] = ops.RowStats(M, C, self.device, eps=1e-5)
-        return self._rowstats[key]
 
     def _transformer(self, p, x, B, H, W, ctx, garment, feats_out, stop_after_feats=None):
         """Transformer2DModel (src/transformerhacked_tryon.py:246-467), NHWC so no permutes."""
@@ -368,14 +332,13 @@ class HipUNet:
         C, N = tf["ch"], H * W
         Np = ops.round16(N)                                  # token rows per image inside the transformer (V^T works in groups of 16 keys)
         g = self._gn(x, None, p + ".norm", 1e-6, False)
-        rs = self._rowstats_buf(B * Np, C) if (self.fuse_ln and self.tryon) else None
         if Np == N:
-            hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32, rowstats_out=rs)
+            hs = ops.linear(g.reshape(B * N, C), sd[p + ".proj_in.weight"], bias=sd[p + ".proj_in.bias"], out_f32=self.stream_f32)
         else:
             # H*W not a multiple of 16 (e.g. 320x320 -> 10x10 tokens at the coarsest level): proj_in as a 1x1 convolution from an N-pixel row
             # to an Np-pixel row per image -- rows N..Np-1 read outside the image (zeros -> bias): finite filler the attention masks as keys
             hs = ops.gemm_conv([ops.SegSpec(g, 0, C)], sd[p + ".proj_in.weight"], B * Np, Ho=1, Wo=Np, Hi=1, Wi=N, bias=sd[p + ".proj_in.bias"],
-                               out_f32=self.stream_f32, rowstats_out=rs)
+                               out_f32=self.stream_f32)
         for blk in tf["blocks"]:
             hs = self._block(blk, hs, B, Np, C, ctx, garment, feats_out, stop_after_feats, last=blk is tf["blocks"][-1], nk=N)
             if hs is None:
@@ -415,7 +378,7 @@ class HipUNet:
                 kg = torch.empty(Bg * N, C, dtype=torch.uint8 if f8 else self.dtype, device=self.device)
                 vtg = torch.empty(Bg, C, N, dtype=torch.uint8 if f8 else self.dtype, device=self.device)
             f8kw = dict(f8=(2.0 ** self.f8_exp[1], 2.0 ** self.f8_exp[2])) if f8 else {}
-            ops.linear(g.reshape(Bg * N, C), blk.get("kv_plain", blk["qkv"][C:]), out=kg, vt=vtg, vt_n0=C, vt_tokens=N, **f8kw)
+            ops.linear(g.reshape(Bg * N, C), blk["qkv"][C:], out=kg, vt=vtg, vt_n0=C, vt_tokens=N, **f8kw)
             res.append((kg, vtg))
         return res
 

@@ -94,11 +94,8 @@ typedef struct {
     int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
                                     the 128x256 and 64x64 ring tiles with register-prefetched fragments; variant 6 = 8-wave forms of the tiles that
-                                    run one workgroup per CU: 128x128 (64x32 per wave) and 320x256 (N = 320 in one weight tile); variant 7 = 128x128
-                                    with INTRA-WORKGROUP SPLIT-K (two 4-wave groups contract alternate k-tiles, partial sums meet in LDS; low nibble
-                                    of the BM field: 1 = register-prefetched fragments) -- the only tile whose summation order differs from the
-                                    others (two partial sums), so its results match theirs to fp32 rounding, not bit for bit; variants 6 / 7 fall
-                                    back to the variant-1 tile for launches with a V^T part; variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
+                                    run one workgroup per CU: 128x128 (64x32 per wave) and 320x256 (N = 320 in one weight tile), falling back to
+                                    the variant-1 tile for launches with a V^T part; variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
                                     of the BM field = placement form 0 | 1; bit 14 of it, tests only: 5 persistent workgroups) and 256x192 -- a PERSISTENT kernel:
                                     min(tiles, CUs) workgroups walk the tile raster.  Bit 15
                                     (0x8000) forces the 8-byte epilogue (measurement only; default: 16-byte accesses when every
@@ -119,21 +116,6 @@ typedef struct {
                                     1868-1880 upcast_vae / force_upcast): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps 16 mantissa bits, and
                                     x.w = hi.w_hi + lo.w_hi + hi.w_lo (+ O(2^-17)) is three K segments of ONE launch: activations [hi | lo] (K-segments
                                     (coff 0, len 2C) and (coff 0, len C)) against weights laid out [w_hi | w_hi | w_lo]; two when w_lo == 0. */
-    /* LayerNorm folded into the GEMMs on either side of it (src/attentionhacked_tryon.py:310,358,390: norm1/2/3 feed to_q|k|v, attn2.to_q,
-       ff.net.0.proj).  LN(x).W^T = rstd[m] * (x . (gamma*W)^T)[m][n] - rstd[m]*mean[m]*s[n] + c[n],  s[n] = sum_k (gamma*W)[n][k],
-       c[n] = sum_k beta[k] W[n][k]: the CONSUMER GEMM runs on the raw hidden state with gamma folded into its weights and applies the
-       per-row / per-column terms to its accumulators before the rest of the epilogue; the per-row statistics come from the PRODUCER
-       GEMM (the to_out / ff.net.2 / proj_in that wrote x).  Every tile of the producer emits, for its rows m and 32-column groups j,
-       the (sum, sum of squares) of the values it STORED: rowstats_out[(m*parts + j)*2 + {0,1}], parts = N/32 (N % 32 == 0, plain
-       16-byte epilogue), as write-through agent-scope stores, then counts itself on rowstats_counter[row tile]; the tile that arrives
-       LAST on a row tile folds that tile's partials in a fixed order (deterministic, whichever tile is last) into
-       rowstats_final[m*2 + {0,1}] = (rstd, -rstd*mean) with rowstats_eps, and resets the counter -- ONE fold per row instead of one
-       per consumer tile.  rowstats_counter: >= ceil(M/64) uint32 words, ZERO before the first launch that uses them (every launch
-       leaves them zero), never shared by two launches that may run concurrently.  The consumer reads ln_rowstats = that [M][2] array
-       (one 8-byte load per row, issued ahead of its main loop) and ln_colvec = [2][N] fp32 {s, c}.  No LayerNorm launch, no
-       normalised copy of x in HBM.  All NULL = off. */
-    float* rowstats_out; float* rowstats_final; uint32_t* rowstats_counter; float rowstats_eps;
-    const float* ln_rowstats; const float* ln_colvec;
     const idmvton_xattn* xattn;  /* mode IDMVTON_EPI_XATTN only (host pointer, read during the call) */
     int32_t colscale_n; float colscale; /* columns n < colscale_n (multiple of 4) of `out` are multiplied by colscale after bias / rowbias and
                                     before the activation / residual, in fp32 (0: off).  Used to hand the attention kernel a q that is
@@ -143,7 +125,7 @@ typedef struct {
                                     receives e4m3(clamp(value * f8_vt_scale)) as [B][N - vt_n0][vt_tokens] bytes in the fp8 kernel's SLOT ORDER (position
                                     64t + 32u + 16kb + 4g + j holds key 64t + 32kb + 8g + 4u + j: exactly what idmvton_quant_f8 mode 1 produces from the
                                     16-bit V^T; vt_perm is ignored).  Scales are powers of two (they ride on the MFMA's E8M0 operands).  Needs the plain
-                                    16-byte epilogue (no GEGLU / residual / fp32 IO / LayerNorm fold / rowstats), vt_tokens % 64 == 0, 16-byte aligned
+                                    16-byte epilogue (no GEGLU / residual / fp32 IO), vt_tokens % 64 == 0, 16-byte aligned
                                     pointers.  One rounding from the fp32 accumulator instead of two (16-bit, then e4m3), no idmvton_quant_f8 launches. */
 } idmvton_gemm_conv_args;
 int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream);

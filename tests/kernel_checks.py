@@ -576,66 +576,6 @@ def check_stream_f32(M, N, K, dtype, dev, tile_hint=0, seed=0):
     return e
 
 
-def check_ln_fold(M, C, N, dtype, dev, mode="plain", tile_hint=0, prod_hint=0, seed=0, B=1, reps=3):
-    """LayerNorm folded into the GEMMs around it (gemm_conv rowstats_* / ln_*): a producer GEMM (+bias +residual) writes the hidden
-    state, its tiles' partial row statistics, and -- the tile that finishes a row tile last -- (rstd, -rstd*mean) per row; the consumer
-    GEMM (plain | qkv = q-scale + transposed V columns | geglu) reads the raw hidden state with gamma-folded weights.  Reference:
-    LayerNorm (fp32) of the stored hidden state, then the projection in fp32.  The pair runs `reps` times on ONE RowStats with fresh
-    data each time: the arrival counters must come back to zero, and no value of an earlier repetition may survive in a cache."""
-    from idm_vton_amd import ops
-    from idm_vton_amd.weights import interleave_geglu
-    stats = ops.RowStats(M, C, dev, eps=1e-5)
-    stats.partials.fill_(float("nan")); stats.final.fill_(float("nan"))
-    e = 0.0
-    for rep in range(reps):
-        sd = seed + 100 * rep
-        a = _r(M, C, dtype=dtype, dev=dev, seed=sd)
-        wp = _r(C, C, dtype=dtype, dev=dev, scale=C ** -0.5, seed=sd + 1)
-        bp = _r(C, dtype=dtype, dev=dev, seed=sd + 2)
-        rsd = _r(M, C, dtype=dtype, dev=dev, scale=2.0 + rep, seed=sd + 3) + 0.6 - 0.5 * rep     # a row mean that is not ~0
-        hs = ops.linear(a, wp, bias=bp, res=rsd, rowstats_out=stats, tile_hint=prod_hint)
-        hf = hs.float()
-        g32 = hf.view(M, C // 32, 32)
-        st_ref = torch.stack([g32.sum(-1), (g32 * g32).sum(-1)], dim=-1)
-        e = max(e, relerr(stats.partials.view(M, C // 32, 2), st_ref) / 1e-5 * TOL[dtype])      # fp32 sums of 32 stored values: <= 1e-5
-        mean = hf.mean(-1)
-        rstd = (hf.var(-1, unbiased=False) + 1e-5).rsqrt()
-        fin_ref = torch.stack([rstd, -rstd * mean], dim=-1)
-        e = max(e, relerr(stats.final.view(M, 2), fin_ref) / 2e-4 * TOL[dtype])                  # E[x^2] - mean^2 in fp32: <= 2e-4
-        if int(stats.counter.abs().max().item()) != 0:
-            return float("inf")                                                                  # a counter was left non-zero
-        gam = _r(C, dtype=dtype, dev=dev, scale=0.3, seed=sd + 4) + 1.0
-        bet = _r(C, dtype=dtype, dev=dev, scale=0.3, seed=sd + 5)
-        n = F.layer_norm(hf, (C,), gam.float(), bet.float(), 1e-5)
-        if mode == "plain":
-            w = _r(N, C, dtype=dtype, dev=dev, scale=C ** -0.5, seed=sd + 6)
-            ws, cv = ops.ln_fold_weights(w, gam, bet)
-            out = ops.linear(hs, ws, ln=(stats, cv), tile_hint=tile_hint)
-            e = max(e, relerr(out, n @ w.float().t()))
-        elif mode == "geglu":
-            inner = N
-            w = _r(2 * inner, C, dtype=dtype, dev=dev, scale=C ** -0.5, seed=sd + 6)
-            b = _r(2 * inner, dtype=dtype, dev=dev, seed=sd + 7)
-            y = n @ w.float().t() + b.float()
-            h, g = y.chunk(2, dim=-1)
-            wi, bi = interleave_geglu(w, b)
-            ws, cv = ops.ln_fold_weights(wi, gam, bet)
-            out = ops.linear(hs, ws, bias=bi, geglu=True, ln=(stats, cv), tile_hint=tile_hint)
-            e = max(e, relerr(out, h * F.gelu(g)))
-        else:        # qkv: columns [0, 2C) normal with the q columns scaled, columns [2C, 3C) transposed in key order
-            Ntok = M // B
-            w = _r(3 * C, C, dtype=dtype, dev=dev, scale=C ** -0.5, seed=sd + 6)
-            ws, cv = ops.ln_fold_weights(w, gam, bet)
-            ref = n @ w.float().t()
-            ref[:, :C] *= ops.QSCALE
-            out = torch.zeros(M, 2 * C, dtype=dtype, device=dev)
-            vt = torch.zeros(B, C, Ntok, dtype=dtype, device=dev)
-            ops.linear(hs, ws, out=out, vt=vt, vt_n0=2 * C, vt_tokens=Ntok, colscale_n=C, colscale=ops.QSCALE, ln=(stats, cv), tile_hint=tile_hint)
-            vt_ref = ops.key_order(ref[:, 2 * C:].reshape(B, Ntok, C).transpose(1, 2).contiguous())
-            e = max(e, relerr(out, ref[:, :2 * C]), relerr(vt, vt_ref))
-    return e
-
-
 def check_groupnorm(B, HW, Cc, dtype, dev, groups=32, silu=True, split=0, eps=1e-5, seed=0):
     from idm_vton_amd import ops
     x = _r(B, HW, Cc, dtype=dtype, dev=dev, scale=2.0, seed=seed) + 0.7
@@ -824,8 +764,9 @@ RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
               # bit 14 of the BM field: 5 persistent workgroups, so these small shapes walk several output tiles per workgroup (cross-tile prefetch)
               (_hint(5, 256, 257 | 0x4000), "h5f1_walk"), (_hint(5, 256, 256 | 0x4000), "h5f0_walk"), (_hint(5, 256, 192 | 0x4000), "h192_walk"),
               (_hint(2, 128, 256), "p128x256"), (_hint(2, 64, 64), "p64x64"),
-              # variant 6: 8-wave 128x128 / the 320-column tile; variant 7: 128x128 with intra-workgroup split-K (low nibble 1: prefetched fragments)
-              (_hint(6, 128, 128), "w8_128x128"), (_hint(6, 320, 256), "w8_320x256"), (_hint(7, 128, 128), "sk128"), (_hint(7, 128, 128 | 1), "sk128pf"),
+              # variant 6: 8-wave 128x128 / the 320-column tile
+              (_hint(6, 128, 128), "w8_128x128"), (_hint(6, 128, 129), "w8p_128x128"), (_hint(6, 128, 130), "w8s4_128x128"), (_hint(6, 320, 256), "w8_320x256"),
+              (_hint(6, 256, 256), "w16_256x256"), (_hint(6, 128, 256), "w16_128x256"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))
 
@@ -945,7 +886,7 @@ def all_checks(dev="cuda"):
         add("quant_f8", lambda dt=dt: check_quant_f8(dt, dev), 0.0)
         # the projections of the fp8 path writing e4m3 themselves (IDMVTON_IO_OUT_F8), on every tile family the tuned table may select
         for hn, hv in (("auto", 0), ("r128x128", _hint(1, 128, 128)), ("r128x256", _hint(1, 128, 256)), ("r256x256", _hint(1, 256, 256)),
-                       ("p128x64", _hint(2, 128, 64)), ("v0_128x128", _hint(0, 128, 128)), ("h256", _hint(5, 256, 256)), ("h256f1", _hint(5, 256, 257)),
+                       ("p64x64", _hint(2, 64, 64)), ("w8_128x128", _hint(6, 128, 128)), ("v0_128x128", _hint(0, 128, 128)), ("h256", _hint(5, 256, 256)), ("h256f1", _hint(5, 256, 257)),
                        ("h192", _hint(5, 256, 192))):
             add(f"gemm_f8_out_{hn}", lambda dt=dt, hv=hv: check_gemm_f8_out(dt, dev, B=2, N=192, C=256, K=320, hint=hv), 0.0)
         add("gemm_f8_out_N768_C640", lambda dt=dt: check_gemm_f8_out(dt, dev, B=4, N=768, C=640, K=640), 0.0)
@@ -975,7 +916,7 @@ def all_checks(dev="cuda"):
         add("attn_self_cfg4_N6144_h10", lambda dt=dt: check_attn_self(2, 10, 6144, dt, dev, n_garm=6144, b0=1))
         add("attn_self_cfg4_N1536_h20", lambda dt=dt: check_attn_self(2, 20, 1536, dt, dev, n_garm=1536, b0=1))
         add("attn_cross_77_16_N768", lambda dt=dt: check_attn_cross(4, 4, 768, dt, dev))
-        for hint, tag in ((0, "auto"), (_hint(1, 128, 64), "128x64"), (_hint(1, 128, 128), "128x128"), (_hint(1, 128, 256), "128x256")):
+        for hint, tag in ((0, "auto"), (_hint(1, 128, 64), "128x64"), (_hint(1, 128, 128), "128x128"), (_hint(1, 128, 256), "128x256"), (_hint(6, 128, 128), "w8_128x128")):
             add(f"xattn_fused_B4_h20_N768_{tag}", lambda dt=dt, hint=hint: check_xattn_fused(4, 20, 768, 1280, dt, dev, tile_hint=hint))
             add(f"xattn_fused_text_only_B2_h4_N96_{tag}", lambda dt=dt, hint=hint: check_xattn_fused(2, 4, 96, 256, dt, dev, n_ip=0, tile_hint=hint))
         add("xattn_fused_B2_h10_N3072_ipscale0.5", lambda dt=dt: check_xattn_fused(2, 10, 3072, 640, dt, dev, ip_scale=0.5))
@@ -983,18 +924,6 @@ def all_checks(dev="cuda"):
         add("attn_cross_scale0.5_N200", lambda dt=dt: check_attn_cross(2, 2, 200, dt, dev, ip_scale=0.5))
         for hint, tag in ((0, "auto"),) + tuple(RING_TILES):
             add(f"stream_f32_768x640x640_{tag}", lambda dt=dt, hint=hint: check_stream_f32(768, 640, 640, dt, dev, tile_hint=hint))
-        for hint, tag in ((0, "auto"),) + tuple(RING_TILES) + (((128 << 16) | 128, "v0_128x128"), ((128 << 16) | 64, "v0_128x64"), ((64 << 16) | 64, "v0_64x64")):
-            add(f"ln_fold_plain_768x640_{tag}", lambda dt=dt, hint=hint: check_ln_fold(768, 640, 640, dt, dev, "plain", tile_hint=hint, prod_hint=hint))
-            add(f"ln_fold_qkv_B2_N384_C640_{tag}", lambda dt=dt, hint=hint: check_ln_fold(768, 640, 0, dt, dev, "qkv", tile_hint=hint, B=2))
-            if hint == 0 or (hint >> 16) & 0xfff >= 128:
-                add(f"ln_fold_geglu_768x640_{tag}", lambda dt=dt, hint=hint: check_ln_fold(768, 640, 2560, dt, dev, "geglu", tile_hint=hint))
-        add("ln_fold_plain_ragged_1000x320x192", lambda dt=dt: check_ln_fold(1000, 320, 192, dt, dev, "plain"))
-        add("ln_fold_plain_3072x1280", lambda dt=dt: check_ln_fold(3072, 1280, 1280, dt, dev, "plain"))
-        add("ln_fold_qkv_B4_N768_C1280", lambda dt=dt: check_ln_fold(3072, 1280, 0, dt, dev, "qkv", B=4))
-        add("ln_fold_geglu_3072x1280", lambda dt=dt: check_ln_fold(3072, 1280, 5120, dt, dev, "geglu"))
-        # the last-arriver hand-off under load: many row tiles spread over all XCDs, six repetitions on one scratch
-        add("ln_fold_plain_12288x640_reps6", lambda dt=dt: check_ln_fold(12288, 640, 640, dt, dev, "plain", reps=6))
-        add("ln_fold_plain_9216x1280_reps6", lambda dt=dt: check_ln_fold(9216, 1280, 1280, dt, dev, "plain", reps=6))
         add("stream_f32_ragged_1000x328x192", lambda dt=dt: check_stream_f32(1000, 328, 192, dt, dev))
         add("stream_f32_3072x1280x5120", lambda dt=dt: check_stream_f32(3072, 1280, 5120, dt, dev))
         add("layernorm_640", lambda dt=dt: check_layernorm(1000, 640, dt, dev))

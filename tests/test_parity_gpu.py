@@ -155,11 +155,10 @@ def test_strength_and_no_cfg_branches_match_oracle(case):
         assert pu.relerr(lat_p, lat_o) <= TOL[dt]["latents"], (case, kw, pu.relerr(lat_p, lat_o))
 
 
-@pytest.mark.parametrize("opt", ["fuse_ln", "stream_f32"])
+@pytest.mark.parametrize("opt", ["stream_f32"])
 def test_engine_options_match_oracle(opt):
-    """The two HipUNet options that are off by default -- LayerNorm folded into the neighbouring GEMMs (fuse_ln) and the fp32
-    residual stream (stream_f32) -- through every stage against the oracle, same bars as the default engine (the kernels behind
-    them are checked tile by tile in tests/kernel_checks.py: check_ln_fold / check_stream_f32)."""
+    """The HipUNet option that is off by default -- the fp32 residual stream (stream_f32) -- through every stage against the oracle, same
+    bars as the default engine (the kernels behind it are checked tile by tile in tests/kernel_checks.py: check_stream_f32)."""
     from tests import parity_checks
     for dtype, kw in ((torch.float16, dict()), (torch.bfloat16, dict()), (torch.float16, dict(use_graph=True, overlap=True))):
         t = TOL[dtype]

@@ -18,13 +18,14 @@ def short(name):
     return re.split(r"[<(]", name)[0][:60]
 
 
-def main():
+GEMM_FAMILIES = ("gemm_conv_kernel", "gemm_lin_kernel", "gemm_xattn_kernel")   # every kernel idmvton_gemm_conv launches
+
+
+def summarise(dirs, label=None):
     """Two aggregates: every dispatch of the run, and (key `denoise_step`) only the dispatches between the first
     pack_input_kernel and the last cfg_step_kernel of the (serial, eager) run = the launches of the denoising steps, the
-    set bench.py's roofline leg covers."""
+    set bench.py's roofline leg covers.  (Also imported by bench.py's own PMC leg.)"""
     agg, step = {}, {}
-    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
-    label = sys.argv[sys.argv.index("--label") + 1] if "--label" in sys.argv else None
     for d in dirs:
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) + \
             glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
@@ -64,15 +65,20 @@ def main():
         res["denoise_step"][k] = e
     # the C-ABI entry idmvton_gemm_conv launches three kernel families since round 4: the compiler-scheduled tiles, the hand-scheduled Linear
     # loop (gemm_lin_kernel) and the projection with the fused cross-attention epilogue (gemm_xattn_kernel): one launch-weighted mean over all
-    fams = [res["denoise_step"][k] for k in ("gemm_conv_kernel", "gemm_lin_kernel", "gemm_xattn_kernel")
-            if "hbm_bytes_per_launch" in res["denoise_step"].get(k, {})]
+    fams = [res["denoise_step"][k] for k in GEMM_FAMILIES if "hbm_bytes_per_launch" in res["denoise_step"].get(k, {})]
     if fams:
         n = sum(f["FETCH_SIZE"]["dispatches"] for f in fams)
         res["gemm_conv_bytes_per_launch"] = sum(f["hbm_bytes_per_launch"] * f["FETCH_SIZE"]["dispatches"] for f in fams) / n
         res["gemm_conv_launches_counted"] = n
     if label:
         res["source"] = label
-    json.dump(res, sys.stdout, indent=1, sort_keys=True)
+    return res
+
+
+def main():
+    dirs = [a for a in sys.argv[1:] if not a.startswith("--") and sys.argv[sys.argv.index(a) - 1] != "--label"]
+    label = sys.argv[sys.argv.index("--label") + 1] if "--label" in sys.argv else None
+    json.dump(summarise(dirs, label), sys.stdout, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
