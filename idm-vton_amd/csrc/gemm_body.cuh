@@ -19,8 +19,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     constexpr int SN = BN / WN, SM = BM / WM;           // wave sub-tile
     constexpr int NI = SN / 32, MI = SM / 32;           // 32x32 MFMA tiles per wave along n / m
     constexpr int WBYTES = BN * 128, XBYTES = BM * 128; // one LDS stage of each operand
-    constexpr int WI = BN / (8 * NW), XI = BM / (8 * NW); // DMA instructions per wave per tile (8 rows each)
-    static_assert(WI >= 1 && XI >= 1 && WI * 8 * NW == BN && XI * 8 * NW == BM, "tile / wave-count mismatch");
+    // DMA instructions per wave per tile (8-row pieces).  Tiles whose piece counts divide by the wave count give every wave a contiguous run of
+    // pieces; the others (320x192 on 12 waves: 40 + 24 pieces) deal the pieces round-robin, some waves issuing one piece fewer -- which a counted
+    // vmcnt cannot express, so those tiles run the two-stage pipeline (vmcnt(0) in front of every barrier).
+    constexpr int PW_ = BN / 8, PX_ = BM / 8;
+    constexpr bool UNEVEN = (PW_ % NW != 0) || (PX_ % NW != 0);
+    constexpr int WI = (PW_ + NW - 1) / NW, XI = (PX_ + NW - 1) / NW;
+    static_assert(BN % 8 == 0 && BM % 8 == 0 && WN * SN == BN && WM * SM == BM && NI * 32 == SN && MI * 32 == SM, "tile / wave-count mismatch");
+    static_assert(!UNEVEN || (V1 && ST == 2), "round-robin piece assignment needs the two-stage ring");
     char* sW = smem;
     char* sX = smem + ST * WBYTES;
 
@@ -31,10 +37,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 
     // ---- loader state: this lane's rows / swizzled chunk for each DMA instruction it issues ----
     const int lrow = lane >> 3, lslot = lane & 7;
+    auto wj = [&](int i) { return UNEVEN ? wave + i * NW : wave * WI + i; };    // index of this wave's i-th weight / activation piece in the tile
+    auto xj = [&](int i) { return UNEVEN ? wave + i * NW : wave * XI + i; };    // (UNEVEN: pieces >= PW_ / PX_ do not exist and are skipped)
     uint32_t w_off[WI];                                  // byte offset of (row, chunk) in W, k0 excluded
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int R = (wave * WI + i) * 8 + lrow;
+        const int R = wj(i) * 8 + lrow;
         const int c = lslot ^ ((R >> 1) & 7);
         w_off[i] = ((uint32_t)(n0 + R) * (uint32_t)p.Ktot + c * 8) * 2u;   // rows >= N fall beyond num_records -> 0
     }
@@ -44,7 +52,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     auto kbyte = [&](int t) -> uint32_t { return (uint32_t)t * 128u; };
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int R = (wave * XI + i) * 8 + lrow;
+        const int R = xj(i) * 8 + lrow;
         const int m = m0 + R;
         x_c8[i] = (lslot ^ ((R >> 1) & 7)) * 8;
         if constexpr (LIN) {
@@ -66,24 +74,30 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
 
     int si = 0, kseg = 0;                                // K-segment cursor of the NEXT tile to issue
     auto issue = [&](int t, int buf) {
-        char* dW = sW + buf * WBYTES + wave * (WI * 1024);
-        char* dX = sX + buf * XBYTES + wave * (XI * 1024);
+        char* dW = sW + buf * WBYTES;
+        char* dX = sX + buf * XBYTES;
 #pragma unroll
-        for (int i = 0; i < WI; ++i) dma16(rs_w, dW + i * 1024, w_off[i] + kbyte(t));
+        for (int i = 0; i < WI; ++i) {
+            if (UNEVEN && wj(i) >= PW_) continue;         // wave-uniform
+            dma16(rs_w, dW + wj(i) * 1024, w_off[i] + kbyte(t));
+        }
         if constexpr (LIN) {
 #pragma unroll
-            for (int i = 0; i < XI; ++i)                  // OOB_SENTINEL + t*128 stays >= 2 GiB > num_records
-                dma16(rs_x0, dX + i * 1024, x_off[i] + kbyte(t));
+            for (int i = 0; i < XI; ++i) {                // OOB_SENTINEL + t*128 stays >= 2 GiB > num_records
+                if (UNEVEN && xj(i) >= PX_) continue;
+                dma16(rs_x0, dX + xj(i) * 1024, x_off[i] + kbyte(t));
+            }
         } else {
             const idmvton_seg sg = p.seg[si];
             const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(sg.ptr, sg.bytes);
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
+                if (UNEVEN && xj(i) >= PX_) continue;
                 int iy = x_oy[i] + sg.dy, ix = x_ox[i] + sg.dx;
                 const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
                 if (p.ups) { iy >>= 1; ix >>= 1; }
                 const uint32_t off = ((uint32_t)(x_pix[i] + iy * p.Wi + ix) * (uint32_t)sg.pitch + sg.coff + kseg + x_c8[i]) * 2u;
-                dma16(rs_x, dX + i * 1024, ok ? off : OOB_SENTINEL);
+                dma16(rs_x, dX + xj(i) * 1024, ok ? off : OOB_SENTINEL);
             }
             kseg += 64;
             if (kseg >= sg.len) { kseg = 0; ++si; }
@@ -98,24 +112,27 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, const
     __amdgpu_buffer_rsrc_t rs_xc = rs_x0;
     auto issue_part = [&](int t, int buf, int s) {
         constexpr int LPT_ = WI + XI;
-        char* dW = sW + buf * WBYTES + wave * (WI * 1024);
-        char* dX = sX + buf * XBYTES + wave * (XI * 1024);
+        char* dW = sW + buf * WBYTES;
+        char* dX = sX + buf * XBYTES;
         if constexpr (!LIN) {
             if (s == 0) { sgc = p.seg[si]; rs_xc = make_rsrc(sgc.ptr, sgc.bytes); }
         }
 #pragma unroll
         for (int j = 0; j < LPT_; ++j) {
             if ((j & 3) != s) continue;
-            if (j < WI) dma16(rs_w, dW + j * 1024, w_off[j] + kbyte(t));
-            else {
+            if (j < WI) {
+                if (UNEVEN && wj(j) >= PW_) continue;
+                dma16(rs_w, dW + wj(j) * 1024, w_off[j] + kbyte(t));
+            } else {
                 const int i = j - WI;
-                if constexpr (LIN) dma16(rs_x0, dX + i * 1024, x_off[i] + kbyte(t));
+                if (UNEVEN && xj(i) >= PX_) continue;
+                if constexpr (LIN) dma16(rs_x0, dX + xj(i) * 1024, x_off[i] + kbyte(t));
                 else {
                     int iy = x_oy[i] + sgc.dy, ix = x_ox[i] + sgc.dx;
                     const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
                     if (p.ups) { iy >>= 1; ix >>= 1; }
                     const uint32_t off = ((uint32_t)(x_pix[i] + iy * p.Wi + ix) * (uint32_t)sgc.pitch + sgc.coff + kseg + x_c8[i]) * 2u;
-                    dma16(rs_xc, dX + i * 1024, ok ? off : OOB_SENTINEL);
+                    dma16(rs_xc, dX + xj(i) * 1024, ok ? off : OOB_SENTINEL);
                 }
             }
         }

@@ -57,6 +57,14 @@ def load_tune(path=TUNE_PATH):
         with open(path) as f:
             t = json.load(f)
         _TUNE = {"gemm": dict(t.get("gemm", {})), "attn": dict(t.get("attn", {}))}
+        # The tuner runs the bf16 engine (keys "1,..."); fp16 launches of the same shapes ("0,...") run the same kernels with the other MFMA
+        # opcode, so an entry measured for one storage type also serves the other unless that one has its own.  (Until round 5 the fp16
+        # engine -- the reference's dtype, bench.py's `fp16` / `fp16_fp8` legs -- ran on the untuned heuristics.)
+        for kind in ("gemm", "attn") if os.environ.get("IDMVTON_TUNE_NO_MIRROR") != "1" else ():     # (the env switch: A/B measurement only)
+            for k, v in list(_TUNE[kind].items()):
+                d, rest = k.split(",", 1)
+                if d in ("0", "1"):
+                    _TUNE[kind].setdefault(("1" if d == "0" else "0") + "," + rest, v)
     return _TUNE
 
 

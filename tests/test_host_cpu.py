@@ -255,8 +255,10 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
     t = json.load(open(ops.TUNE_PATH))
     gemm_ok = {0: {(128, 128), (128, 64), (64, 64)},
                1: {(256, 256), (128, 256), (128, 128), (128, 64), (64, 64)},
-               2: {(256, 256), (128, 256), (128, 64), (64, 64)},
-               5: {(256, 256), (256, 257), (256, 192)}}           # hand-scheduled Linear loop: 256x256 placement forms 0 / 1 (low nibble of BM), 256x192
+               2: {(128, 256), (64, 64)},
+               5: {(256, 256), (256, 257), (256, 192)},           # hand-scheduled Linear loop: 256x256 placement forms 0 / 1 (low nibble of BM), 256x192
+               # more waves per workgroup (csrc/gemm_tiles_w8.hip): 128x128 forms 0 / 1 / 2, the 320-column tiles, 16-wave 256x256 / 128x256
+               6: {(128, 128), (128, 129), (128, 130), (320, 256), (320, 192), (256, 256), (128, 256)}}
     assert t["gemm"] and t["attn"]
     for key, h in t["gemm"].items():
         f = [int(x) for x in key.split(",")]
@@ -264,9 +266,9 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
         variant, bn, bm = (h >> 28) & 0xf, (h >> 16) & 0xfff, h & 0xffff
         assert (bn, bm) in gemm_ok.get(variant, ()), (key, h)
         if f[8] == 1:
-            assert bn >= 128, (key, "GEGLU needs 64-row wave tiles")
+            assert bn >= 128 and bn != 320, (key, "GEGLU needs 64-row wave tiles with an even number of 32-column blocks")
         if f[8] == 4:
-            assert bn == 128 and variant in (1, 2), (key, "fused cross-attention: waves own 64 columns")
+            assert bn == 128 and (variant in (1, 2) or (variant == 6 and bm == 128)), (key, "fused cross-attention: waves own 64 columns")
         # variant 5 on a launch that is not a plain Linear (e.g. the split-precision P.V product: 2 K-segments) is legal: launch_gemm runs it on the
         # compiler-scheduled tile of the same / the nearest shape (csrc/gemm_conv.hip), which is what the tuner then measured
     for key, v in t["attn"].items():
