@@ -62,14 +62,14 @@ static int launch_gemm(const GemmParams& p0, bool bf16, int variant, int bn, int
     } else if (variant == 6) {
         // 8-wave forms of tiles that have one workgroup per CU: 128x128 as 2 x 4 waves of 64x32 (two waves per SIMD on one shared k-tile: somebody
         // to cover the fragment-read / DMA / barrier waits of the 4-wave tile) and 320x256 / 320x192 (N = 320 in ONE weight tile: the 128-column
-        // tiles compute 384 columns for it; 320x192 = 12 waves of 160x32, M = 49152 -> 256 tiles where 320x256 gives 192), 16-wave 256x256 / 128x256.  No V^T part; the 10-accumulator 320-column wave tile only has the 16-byte epilogue and no GEGLU pairing
-        // (gemm_common.cuh).  Launches they cannot take run on the plain ring tile.
+        // tiles compute 384 columns for it; 320x192 = 12 waves of 160x32, M = 49152 -> 256 tiles where 320x256 gives 192), 16-wave 256x256 / 128x256.  The 320-column tiles take no V^T part and only the 16-byte epilogue, no GEGLU pairing
+        // (gemm_common.cuh): launches they cannot take run on the plain ring tile.
         // (Measured with them and removed, profiles/r05_tune_report_v1_new_tiles.json: 128x128 with INTRA-WORKGROUP SPLIT-K -- two 4-wave groups
         //  on alternate k-tiles, two LDS rings, partial sums exchanged through LDS -- 6-20 % SLOWER than the 4-wave ring tile on every shape.)
         const int form6 = bm & 15;                       // low nibble of the BM field: form of the 128x128 tile (gemm_tiles_w8.hip)
         bm &= ~15;
         p.tiles_m = (p.M + bm - 1) / bm;
-        if (p.vt || (bn == 320 && (!p.wide || p.out8 || p.mode == IDMVTON_EPI_GEGLU))) {
+        if (bn == 320 && (p.vt || !p.wide || p.out8 || p.mode == IDMVTON_EPI_GEGLU)) {
             const int fbn = bn == 320 ? 128 : bn, fbm = bn == 320 ? 256 : bm;
             p.tiles_n = (p.N + fbn - 1) / fbn;
             p.tiles_m = (p.M + fbm - 1) / fbm;

@@ -95,7 +95,7 @@ typedef struct {
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
                                     the 128x256 and 64x64 ring tiles with register-prefetched fragments; variant 6 = 8-wave forms of the tiles that
                                     run one workgroup per CU: 128x128 (64x32 per wave; low nibble of BM: 1 = prefetched fragments, 2 = 4-stage ring), 320x256 and
-                                    320x192 (N = 320 in one weight tile; 8 / 12 waves), and 16-wave 256x256 / 128x256, falling back to
+                                    320x192 (N = 320 in one weight tile; 8 (BM low nibble 1: 16) / 12 waves), 12-wave 256x192 and 16-wave 256x256 / 128x256; the 320-column tiles fall back to
                                     the variant-1 tile for launches with a V^T part; variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
                                     of the BM field = placement form 0 | 1; bit 14 of it, tests only: 5 persistent workgroups) and 256x192 -- a PERSISTENT kernel:
                                     min(tiles, CUs) workgroups walk the tile raster.  Bit 15
