@@ -268,7 +268,8 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
         if f[8] == 1:
             assert bn >= 128 and bn != 320, (key, "GEGLU needs 64-row wave tiles with an even number of 32-column blocks")
         if f[8] == 4:
-            assert bn == 128 and (variant in (1, 2) or (variant == 6 and bm == 128)), (key, "fused cross-attention: waves own 64 columns")
+            # (the launcher picks the fused cross-attention tile by BN x BM alone; variant 6 selects the 8-wave form of 128x128)
+            assert bn == 128 and bm in (64, 128, 256) and (variant != 6 or bm == 128), (key, "fused cross-attention: waves own 64 columns")
         # variant 5 on a launch that is not a plain Linear (e.g. the split-precision P.V product: 2 K-segments) is legal: launch_gemm runs it on the
         # compiler-scheduled tile of the same / the nearest shape (csrc/gemm_conv.hip), which is what the tuner then measured
     for key, v in t["attn"].items():
