@@ -60,10 +60,11 @@ static int launch_gemm(const GemmParams& p0, bool bf16, int variant, int bn, int
             rc = gemm_tiles_v1(p, bf16, 128, 256, lin, st);
         }
     } else if (variant == 6) {
-        // 8-wave forms of tiles that have one workgroup per CU: 128x128 as 2 x 4 waves of 64x32 (two waves per SIMD on one shared k-tile: somebody
-        // to cover the fragment-read / DMA / barrier waits of the 4-wave tile) and 320x256 / 320x192 (N = 320 in ONE weight tile: the 128-column
-        // tiles compute 384 columns for it; 320x192 = 12 waves of 160x32, M = 49152 -> 256 tiles where 320x256 gives 192), 16-wave 256x256 / 128x256.  The 320-column tiles take no V^T part and only the 16-byte epilogue, no GEGLU pairing
-        // (gemm_common.cuh): launches they cannot take run on the plain ring tile.
+        // More waves per workgroup on the tiles that run ONE workgroup per CU (gemm_tiles_w8.hip): 128x128 as 2 x 4 waves of 64x32 (two waves per SIMD
+        // on one shared k-tile: somebody to cover the fragment-read / DMA / barrier waits of the 4-wave tile), 320x192 as 12 waves of 160x32 (N = 320 in
+        // ONE weight tile -- the 128-column tiles compute 384 columns for it -- and M = 49152 gives exactly 256 tiles), 256x192 as 12 waves of 64x64,
+        // 256x256 / 128x256 as 16 waves.  The 320-column tile takes no V^T part and only the 16-byte epilogue, no GEGLU pairing (gemm_common.cuh):
+        // launches it cannot take run on the plain ring tile.
         // (Measured with them and removed, profiles/r05_tune_report_v1_new_tiles.json: 128x128 with INTRA-WORKGROUP SPLIT-K -- two 4-wave groups
         //  on alternate k-tiles, two LDS rings, partial sums exchanged through LDS -- 6-20 % SLOWER than the 4-wave ring tile on every shape.)
         const int form6 = bm & 15;                       // low nibble of the BM field: form of the 128x128 tile (gemm_tiles_w8.hip)
@@ -204,6 +205,14 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     // no hint and the heuristic chose the 256x256 tile for a plain Linear: the hand-scheduled loop (gemm_lin.hip) won on every such shape it
     // was measured on (profiles/r04_gemm_probe_*.log: +5..11 % over the compiler-scheduled tile)
     if (!a->tile_hint && bn == 256 && bm == 256 && lin) { variant = 5; bm = 257; }
+    else if (!a->tile_hint && !xattn) {
+        // ... and the round-5 measurements for everything else the table has no entry for (profiles/r05_tune_report_v{1..4}*.json: every one of
+        // these won or tied on each shape it was tried on): a convolution on the 256x256 tile -> its 16-wave form; the one-workgroup-per-CU 128x128
+        // tile -> its 8-wave form; N = 320 (SDXL's first level) -> the 320-column tile when the launch can take it and fills the chip.
+        if (bn == 256 && bm == 256) variant = 6;
+        else if (bn == 128 && bm == 128) variant = 6;
+        if (a->N > 256 && a->N <= 320 && p.wide && !a->vt && !geglu && !p.out8 && (a->M + 191) / 192 >= 200) { variant = 6; bn = 320; bm = 192; }
+    }
     hipStream_t st = (hipStream_t)stream;
     return launch_gemm(p, a->dtype == IDMVTON_BF16, variant, bn, bm, lin, st);
 }

@@ -7,10 +7,7 @@ template <typename T>
 static int run(const GemmParams& p, int bn, int bm, int form, bool lin, hipStream_t st) {
     if (bn == 128 && bm == 128 && form == 0) launch_cfg<T, 128, 128, 2, 4, 3, true, 2>(p, lin, st);          // 64x32 per wave, two waves per SIMD on one k-tile
     else if (bn == 128 && bm == 128 && form == 1) launch_cfg<T, 128, 128, 2, 4, 3, true, 2, true>(p, lin, st);
-    else if (bn == 128 && bm == 128 && form == 2) launch_cfg<T, 128, 128, 2, 4, 4, true, 2>(p, lin, st);
-    else if (bn == 320 && bm == 256 && form == 0) launch_cfg<T, 320, 256, 2, 4, 2, true, 2>(p, lin, st);                  // 160x64 per wave (5 x 2 MFMA tiles), 144 KiB
     else if (bn == 320 && bm == 192) launch_cfg<T, 320, 192, 2, 6, 2, true, 3>(p, lin, st);                  // 12 waves of 160x32: M = 49152 gives 256 tiles (320x256: 192)
-    else if (bn == 320 && bm == 256 && form == 1) launch_cfg<T, 320, 256, 2, 8, 2, true, 4>(p, lin, st);     // 16 waves of 160x32
     else if (bn == 256 && bm == 192) launch_cfg<T, 256, 192, 4, 3, 2, true, 3>(p, lin, st);                  // 12 waves of 64x64: 3072 x 3840 / 9216 x 1280 -> 240 tiles
     else if (bn == 256 && bm == 256) launch_cfg<T, 256, 256, 4, 4, 2, true, 4>(p, lin, st);                  // 16 waves of 64x64: four waves per SIMD
     else if (bn == 128 && bm == 256) launch_cfg<T, 128, 256, 2, 8, 3, true, 4>(p, lin, st);                  // 16 waves of 64x32

@@ -93,10 +93,10 @@ typedef struct {
     void* vt; int32_t vt_n0; int32_t vt_tokens;
     int32_t tile_hint;           /* 0 = auto; else (variant<<28)|(BN<<16)|BM: variant 0 = 2-stage 4-wave tiles 128x128,
                                     128x64, 64x64; variant 1 = LDS-ring tiles 256x256, 128x256 (8 waves), 128x128, 128x64, 64x64; variant 2 =
-                                    the 128x256 and 64x64 ring tiles with register-prefetched fragments; variant 6 = 8-wave forms of the tiles that
-                                    run one workgroup per CU: 128x128 (64x32 per wave; low nibble of BM: 1 = prefetched fragments, 2 = 4-stage ring), 320x256 and
-                                    320x192 (N = 320 in one weight tile; 8 (BM low nibble 1: 16) / 12 waves), 12-wave 256x192 and 16-wave 256x256 / 128x256; the 320-column tiles fall back to
-                                    the variant-1 tile for launches with a V^T part; variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
+                                    the 128x256 and 64x64 ring tiles with register-prefetched fragments; variant 6 = more waves per workgroup on the tiles that
+                                    run one workgroup per CU (csrc/gemm_tiles_w8.hip): 8-wave 128x128 (64x32 per wave; low nibble of BM: 1 = prefetched
+                                    fragments), 12-wave 320x192 (N = 320 in ONE weight tile; no V^T part / GEGLU: such launches fall back to the
+                                    variant-1 128x256 tile) and 256x192, 16-wave 256x256 and 128x256; variant 5 = the hand-scheduled Linear loop (csrc/gemm_lin.hip): 256x256 (low nibble
                                     of the BM field = placement form 0 | 1; bit 14 of it, tests only: 5 persistent workgroups) and 256x192 -- a PERSISTENT kernel:
                                     min(tiles, CUs) workgroups walk the tile raster.  Bit 15
                                     (0x8000) forces the 8-byte epilogue (measurement only; default: 16-byte accesses when every

@@ -764,8 +764,8 @@ RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
               # bit 14 of the BM field: 5 persistent workgroups, so these small shapes walk several output tiles per workgroup (cross-tile prefetch)
               (_hint(5, 256, 257 | 0x4000), "h5f1_walk"), (_hint(5, 256, 256 | 0x4000), "h5f0_walk"), (_hint(5, 256, 192 | 0x4000), "h192_walk"),
               (_hint(2, 128, 256), "p128x256"), (_hint(2, 64, 64), "p64x64"),
-              # variant 6: 8-wave 128x128 / the 320-column tile
-              (_hint(6, 128, 128), "w8_128x128"), (_hint(6, 128, 129), "w8p_128x128"), (_hint(6, 128, 130), "w8s4_128x128"), (_hint(6, 320, 256), "w8_320x256"), (_hint(6, 320, 192), "w12_320x192"), (_hint(6, 320, 257), "w16_320x256"), (_hint(6, 256, 192), "w12_256x192"),
+              # variant 6: 8-wave 128x128 (2 forms), the 12-wave 320x192 / 256x192 tiles, 16-wave 256x256 / 128x256
+              (_hint(6, 128, 128), "w8_128x128"), (_hint(6, 128, 129), "w8p_128x128"), (_hint(6, 320, 192), "w12_320x192"), (_hint(6, 256, 192), "w12_256x192"),
               (_hint(6, 256, 256), "w16_256x256"), (_hint(6, 128, 256), "w16_128x256"),
               (_hint(1, 256, 256), "r256x256"), (_hint(1, 128, 256), "r128x256"), (_hint(1, 128, 128), "r128x128"), (_hint(1, 128, 64), "r128x64"),
               (_hint(1, 64, 64), "r64x64"))

@@ -257,8 +257,8 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
                1: {(256, 256), (128, 256), (128, 128), (128, 64), (64, 64)},
                2: {(128, 256), (64, 64)},
                5: {(256, 256), (256, 257), (256, 192)},           # hand-scheduled Linear loop: 256x256 placement forms 0 / 1 (low nibble of BM), 256x192
-               # more waves per workgroup (csrc/gemm_tiles_w8.hip): 128x128 forms 0 / 1 / 2, the 320-column tiles, 16-wave 256x256 / 128x256
-               6: {(128, 128), (128, 129), (128, 130), (320, 256), (320, 257), (320, 192), (256, 192), (256, 256), (128, 256)}}
+               # more waves per workgroup (csrc/gemm_tiles_w8.hip): 8-wave 128x128 forms 0 / 1, 12-wave 320x192 / 256x192, 16-wave 256x256 / 128x256
+               6: {(128, 128), (128, 129), (320, 192), (256, 192), (256, 256), (128, 256)}}
     assert t["gemm"] and t["attn"]
     for key, h in t["gemm"].items():
         f = [int(x) for x in key.split(",")]

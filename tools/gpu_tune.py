@@ -26,10 +26,9 @@ GEMM_CANDS = [("v0_128x128", hint(0, 128, 128)), ("v0_128x64", hint(0, 128, 64))
               ("r_256x256", hint(1, 256, 256)), ("r_128x256", hint(1, 128, 256)), ("r_128x128", hint(1, 128, 128)), ("r_128x64", hint(1, 128, 64)),
               ("r_64x64", hint(1, 64, 64)), ("h_256x256", hint(5, 256, 257)), ("h_256x192", hint(5, 256, 192)),   # h = the hand-scheduled Linear loop (csrc/gemm_lin.hip)
               # round 5: 8-wave forms of the one-workgroup-per-CU tiles
-              # (w8: 128x128 as 8 waves of 64x32 -- p = prefetched fragments, s4 = 4-stage ring; also the 8-wave form of the fused cross-attention
-              # projection; 320x256: N = 320 in one weight tile) and 16-wave forms of the 256-row tiles (w16: 64x64 / 64x32 per wave)
-              ("w8_128x128", hint(6, 128, 128)), ("w8p_128x128", hint(6, 128, 129)), ("w8s4_128x128", hint(6, 128, 130)), ("w8_320x256", hint(6, 320, 256)), ("w12_320x192", hint(6, 320, 192)),
-              ("w16_320x256", hint(6, 320, 257)), ("w12_256x192", hint(6, 256, 192)),
+              # (w8: 128x128 as 8 waves of 64x32 -- p = prefetched fragments; also the 8-wave form of the fused cross-attention projection; w12: 320x192
+              # = N = 320 in one weight tile, and 256x192, 12 waves each) and 16-wave forms of the 256-row tiles (w16: 64x64 / 64x32 per wave)
+              ("w8_128x128", hint(6, 128, 128)), ("w8p_128x128", hint(6, 128, 129)), ("w12_320x192", hint(6, 320, 192)), ("w12_256x192", hint(6, 256, 192)),
               ("w16_256x256", hint(6, 256, 256)), ("w16_128x256", hint(6, 128, 256))]
 def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
     return ((thr << 2 | noprio << 1 | pair) << 24) | ((3 if deep else 2) << 16) | (stages << 8) | 8
