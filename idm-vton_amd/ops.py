@@ -173,8 +173,6 @@ def gemm_conv(segs, w, M, *, Ho=1, Wo=None, Hi=1, Wi=None, stride=1, ups=False, 
             xbytes += sg.t.numel() * sg.t.element_size()
     esz = w.element_size()
     obytes = (M * (N // 2 if geglu else N)) * (out.element_size() if out is not None else esz) + (M * N * res.element_size() if res is not None else 0)
-    if PREFETCH is not None:
-        _prefetch_hook(w)
     _call("idmvton_gemm_conv", a, flops=2.0 * M * N * Ktot + xflops, bytes_=float(xbytes + N * Ktot * esz + obytes))
     return out
 
@@ -428,70 +426,6 @@ def split(x, dtype, mode=ffi.SPLIT_ACT):
     a.src, a.lds, a.dst, a.ldd = _ptr(x), x.stride(0), _ptr(out), out.stride(0)
     _call("idmvton_split", a, bytes_=float(rows * cols * 4 + out.numel() * out.element_size()))
     return out
-
-
-# ---- weight prefetch beside the GEMM chain (TryonEngine._tryon_main) --------------------------------------------------------------
-# A denoising step streams ~5 GB of TryonNet weights from HBM, 20x the Infinity Cache: every GEMM finds its weights cold, and the same
-# launches measure 2.4 ms per step faster with the weights cache resident (profiles/r04_tune_report_v2.json vs ..._v3_cold_weights.json).
-# With a schedule recorded on the first pass (the launch sequence of a step is fixed), launch j forks a tiny kernel on a side stream that
-# touches the weights of launch j + ahead while launch j runs; the side stream joins at the end of the step, so the whole thing is also
-# capturable as a branch of the step's hipGraph.  Results cannot change (read-only touches).
-PREFETCH = None
-
-
-class weight_prefetch:
-    """`with weight_prefetch(state):` around one pass of a fixed launch sequence.  state = dict(stream=, ahead=, blocks=, min_bytes=,
-    sched=None): the first pass records the (pointer, bytes) of every gemm_conv weight, later passes prefetch.  state None = off."""
-
-    def __init__(self, state):
-        self.state = state
-
-    def __enter__(self):
-        global PREFETCH
-        st = self.state
-        if st is not None:
-            st["idx"] = 0
-            st["rec"] = [] if st.get("sched") is None else None
-            st["forked"] = False
-            PREFETCH = st
-        return self
-
-    def __exit__(self, *exc):
-        global PREFETCH
-        st = self.state
-        if st is not None:
-            PREFETCH = None
-            if st["rec"] is not None:
-                st["sched"], st["rec"] = st["rec"], None
-            else:
-                if st["idx"] != len(st["sched"]):            # another launch sequence than the recorded one: record again next time
-                    st["sched"] = None
-                if st["forked"]:
-                    torch.cuda.current_stream().wait_stream(st["stream"])     # join (inside a capture: closes the branch)
-        return False
-
-
-def _prefetch_hook(w):
-    st = PREFETCH
-    if st["rec"] is not None:
-        st["rec"].append((w.data_ptr(), w.numel() * w.element_size()))
-        return
-    j = st["idx"]
-    st["idx"] = j + 1
-    sched = st["sched"]
-    if j >= len(sched) or sched[j][0] != w.data_ptr():       # not the recorded sequence
-        st["idx"] = -(1 << 30)
-        return
-    ptr, nbytes = sched[(j + st["ahead"]) % len(sched)]      # the tail of a step warms the head of the next one
-    if nbytes < st["min_bytes"]:
-        return
-    ev = torch.cuda.Event()
-    ev.record()                                              # everything before launch j on the current stream
-    st["stream"].wait_event(ev)
-    st["forked"] = True
-    rc = ffi.lib().idmvton_prefetch(C.c_void_p(ptr), C.c_uint64(nbytes), st["blocks"], C.c_void_p(st["stream"].cuda_stream))
-    if rc != 0:
-        raise RuntimeError(ffi.lib().idmvton_last_error().decode())
 
 
 def prefetch(t, blocks=0, stream=None):

@@ -15,8 +15,6 @@ timesteps -- because only the first block's GarmentNet batch cannot hide behind 
 one-timestep first block 7.5 ms of a call are exposed instead of the 45 ms of a six-timestep batch, and each later batch is
 shorter than the TryonNet steps of the block before it.  Every batch runs at its exact size (no padded timesteps).
 """
-import os
-
 import torch
 
 from . import ops
@@ -39,7 +37,6 @@ class TryonEngine:
         self.dtype, self.device = dtype, torch.device(device)
         self._graphs = {}
         self._set_shapes = {}
-        self._pf = {}                                        # weight-prefetch schedules per shape (_prefetch_state)
         self._side = None
         self.garment_steps = 6                               # timesteps per GarmentNet batch (see the module docstring)
         self.ramp = True                                     # first blocks of 1, 2, 4 timesteps
@@ -169,23 +166,9 @@ class TryonEngine:
     def _tryon_main(self, st, temb_t, coef, noise, kv_j):
         B, h, w = st["B"], st["h"], st["w"]
         ops.pack_input(st["latents"], st["cond"], st["x_in"])                              # :1769,1777
-        with ops.weight_prefetch(self._prefetch_state(B, h, w)):                           # (off unless IDMVTON_PREFETCH is set: see there)
-            eps, _ = self.unet.forward(st["x_in"], temb_t, st["ctx_t"], 2 * B, h, w, garment_kv=kv_j)    # :1796-1808
+        eps, _ = self.unet.forward(st["x_in"], temb_t, st["ctx_t"], 2 * B, h, w, garment_kv=kv_j)        # :1796-1808
         ops.cfg_step(eps, st["latents"], noise, coef)                                      # :1814-1823
         return eps
-
-    def _prefetch_state(self, B, h, w):
-        """Weight prefetch beside TryonNet's GEMM chain (ops.weight_prefetch): IDMVTON_PREFETCH="ahead[,blocks[,min_kib]]" turns it on (e.g.
-        "2" = touch the weights of the launch after next with 64 workgroups while the current launch runs).  One schedule per shape."""
-        spec = os.environ.get("IDMVTON_PREFETCH", "")
-        if not spec or spec == "0":
-            return None
-        key = (B, h, w)
-        if key not in self._pf:
-            f = [int(x) for x in spec.split(",")]
-            self._pf[key] = dict(stream=torch.cuda.Stream(), ahead=max(1, f[0]), blocks=f[1] if len(f) > 1 else 64,
-                                 min_bytes=(f[2] if len(f) > 2 else 512) << 10, sched=None)
-        return self._pf[key]
 
     def _new_set(self, st, like=None, run=True):
         """A persistent {70 features, 70 (K, V^T)} set for up to k timesteps + per-timestep views of its K / V^T.  The tensor shapes
