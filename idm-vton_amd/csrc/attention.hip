@@ -416,14 +416,23 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
     // NEGM: -m_run lives in 16 registers and is subtracted by the MFMA (C operand of the first QK^T MFMA).  Only the 256-register
     // build has room for it; the 128-register build subtracts in the softmax (v_fma + v_exp per element instead of v_exp).
     constexpr bool NEGM = DEEP;
-    f32x16 oacc[2], sacc[2], negm;
-    v8 pf[4];
+    // LSUM: the softmax denominator is accumulated BY THE MATRIX PIPE: one more MFMA per PV k-step with an all-ones A operand gives, in every
+    // row of a 32x32 accumulator, the column sums of P^T = this lane's row sum of P over the tile's 64 keys (both half-waves' keys: no
+    // cross-half exchange at the end).  The ablation builds show the kernel bound by its VALU block with the MFMAs entirely hidden
+    // (profiles/r05_pmc_attention_variants.txt: the kernel without any MFMA takes the same time), so 4 more MFMAs per tile for 32 fewer
+    // VALU adds per lane and tile is the right trade -- in the 256-register build only: the accumulator costs 16 registers the 128-register
+    // build does not have.  l then sums the ROUNDED probabilities, the same values the numerator's P.V product uses.
+    constexpr bool LSUM = DEEP;
+    f32x16 oacc[2], sacc[2], negm, lacc;
+    v8 pf[4], ones;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[db][r] = 0.f; sacc[db][r] = 0.f; }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { negm[r] = 0.f; lacc[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -436,7 +445,13 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
         int nz = 0;
         if (p.nseg > 0 && !pres0) nz += p.nk[0];
         if (p.nseg > 1 && !pres1) nz += p.nk[1];
-        if (nz > 0) { l_run = u == 0 ? (float)nz : 0.f; thr_cur = thr; floor_cur = 0.f; }
+        if (nz > 0) {
+            l_run = u == 0 ? (float)nz : 0.f; thr_cur = thr; floor_cur = 0.f;
+            if constexpr (LSUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lacc[r] = (float)nz;
+            }
+        }
     }
 
 #pragma unroll
@@ -473,6 +488,7 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
             }
             oacc[0] = VT<T>::mfma(vf[0][i], pf[i], oacc[0]);
             oacc[1] = VT<T>::mfma(vf[1][i], pf[i], oacc[1]);
+            if constexpr (LSUM) lacc = VT<T>::mfma(ones, pf[i], lacc);
             if (i == 0 && NEGM) {                        // S' = K.Q^T - m_run: the max subtraction rides on the accumulator input
                 sacc[0] = VT<T>::mfma(kf[0][0], qf[0], negm);
                 sacc[1] = VT<T>::mfma(kf[1][0], qf[0], negm);
@@ -517,6 +533,10 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
             const float delta = fmaxf(mx, floor_cur);    // later tiles: the max never moves down
             const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 0.f));   // (first tile: O = l = 0, keep alpha finite)
             l_run *= alpha;
+            if constexpr (LSUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+            }
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -534,10 +554,10 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(NEGM ? sacc[kb][r] : fmaf(sacc[kb][r], cs, -m_run));
-                if (r & 1) ps1 += pv; else ps0 += pv;
+                if constexpr (!LSUM) { if (r & 1) ps1 += pv; else ps0 += pv; }
                 pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
             }
-        l_run += ps0 + ps1;
+        if constexpr (!LSUM) l_run += ps0 + ps1;
     };
 
     // Phase 2s starts with `sync_stage`: wait until this wave's share of stage s has landed (stages s .. s+ST-2 are outstanding,
@@ -581,7 +601,7 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
     }
 
     // ---- finalise and store: lane holds O[q][h*64 + db*32 + 8g + 4u + j] ----
-    const float lt = xhalf_sum(l_run);
+    const float lt = LSUM ? lacc[0] : xhalf_sum(l_run);     // (LSUM: every row of the accumulator holds this lane's query-row sum over all keys)
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     if (q_row < p.Nq) {
         T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 8 * u;
