@@ -349,8 +349,11 @@ class StableDiffusionXLInpaintPipeline:
                  pooled_prompt_embeds_c=None, callback_on_step_end=None, callback_on_step_end_tensor_inputs=["latents"],
                  **kwargs):
         callback_steps = kwargs.pop("callback_steps", None)
-        if kwargs.pop("callback", None) is not None or callback_on_step_end is not None:
-            raise NotImplementedError("per-step callbacks would break the captured hipGraph loop and are not supported")
+        callback = kwargs.pop("callback", None)              # deprecated form, still honoured by the reference (:1855-1863)
+        self._interrupt = False                              # :1519
+        if callback_on_step_end is not None and any(k != "latents" for k in (callback_on_step_end_tensor_inputs or [])):
+            raise NotImplementedError("callback_on_step_end_tensor_inputs other than 'latents': the text / image conditioning is projected once "
+                                      "per call (step-invariant K/V tables), a callback cannot replace it between two steps")
         for name, val, default in (("masked_image_latents", masked_image_latents, None), ("padding_mask_crop", padding_mask_crop, None),
                                    ("timesteps", timesteps, None), ("denoising_start", denoising_start, None),
                                    ("denoising_end", denoising_end, None), ("cross_attention_kwargs", cross_attention_kwargs, None),
@@ -444,7 +447,24 @@ class StableDiffusionXLInpaintPipeline:
                     strength=strength, scheduler=kind, height=height, width=width)
         if isinstance(getattr(self, "trace_call", None), dict):    # test hook: what crossed the engine boundary (an oracle can replay it)
             self.trace_call.update(call)
-        lat = eng(image_dtype=prompt_embeds.dtype, return_latents=True, use_graph=self.use_graph, overlap=self.overlap, **call)
+        on_step = None
+        if callback_on_step_end is not None or callback is not None:
+            # host code between two steps (tryon_pipeline.py:1840-1863) and `interrupt` (:1766-1767): the engine runs its serial un-captured loop
+            # (same kernels, bit-identical latents: tests/test_parity_gpu.py) and hands the live fp32 latents over after every step
+            def on_step(i, t, lat, _dt=prompt_embeds.dtype):
+                tt = torch.tensor(t, device=lat.device)
+                if callback_on_step_end is not None:
+                    view = lat.to(_dt)
+                    outs = callback_on_step_end(self, i, tt, {"latents": view} if callback_on_step_end_tensor_inputs else {}) or {}
+                    new = outs.pop("latents", view)
+                    if new is not view:
+                        lat.copy_(new.to(lat.device, lat.dtype))
+                    if outs:
+                        raise NotImplementedError(f"callback_on_step_end returned {sorted(outs)}: only 'latents' can be replaced between steps")
+                if callback is not None and i % (callback_steps or 1) == 0:
+                    callback(i, tt, lat.to(_dt))                                                 # :1859-1863 (scheduler order 1)
+                return self._interrupt                                                            # :1766-1767: the remaining steps are skipped
+        lat = eng(image_dtype=prompt_embeds.dtype, return_latents=True, use_graph=self.use_graph, overlap=self.overlap, on_step=on_step, **call)
         if output_type == "latent":
             return (lat.clone(),)
         out = eng.decode(lat)                                                                    # :1876 + postprocess

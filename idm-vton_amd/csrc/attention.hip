@@ -619,6 +619,314 @@ __global__ __launch_bounds__(512, DEEP ? 2 : 4) void attn_pp_kernel(const AttnPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_pf_kernel: the ping-pong kernel with every MFMA block reduced to its MFMAs.
+//
+// attn_pp_kernel<DEEP> opens each MFMA block with the block's 16 ds_read_b128 and their latency, with the matrix pipe of that SIMD idle
+// (the partner wave is in its VALU block) -- once per phase, two phases per tile.  Here a group reads the fragments of its NEXT MFMA block
+// during its own VALU block, one phase early, into 64 registers that stay live across the barrier: an MFMA block is then 20 (LSUM) / 16
+// back-to-back MFMAs on operands that are already in registers, and the LDS reads, the LDS-DMA issue and the -m_run splat that seeds the
+// QK^T accumulators (the 8 v_mov_b64 hipcc put between the MFMAs of the older kernel) all sit beside the softmax in the VALU block.
+// That needs the tile in LDS one phase earlier: 3-stage ring, stage s = { K(s) | V^T(s-1) } in buffer s % 3,
+//     phase A_s : group 0  MFMA block s                       | group 1  reads F1(s) (stage s), softmax(s-1)
+//     phase B_s : group 0  reads F0(s+1) (stage s+1), softmax(s) | group 1  MFMA block s
+// Barrier A_s only aligns the phases; barrier M_s (between A_s and B_s) is where every wave has waited for its share of stage s+1
+// (counted vmcnt: stage s+2 stays in flight) and after which buffer s % 3 (last read in A_s) is refilled with stage s+3.
+// Always with q pre-multiplied by softmax_scale * log2(e) (the running max is subtracted by seeding the accumulator with -m_run).
+#ifdef ATTN_DBG
+// Anatomy build (tools only, -DATTN_DBG): every wave sums, over its tile walk, the cycles it spends in its phase-A work, waiting at barrier M,
+// in its phase-B work and waiting at barrier A (s_memtime after each barrier release and before each arrival; ~50 cycles each on the path).
+__device__ unsigned long long g_attn_dbg[4096 * 8 * 8];
+extern "C" int idmvton_attn_dbg_read(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_dbg), bytes); }
+#define DBG_STAMP(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); dbg_acc[slot] += t_ - dbg_t; dbg_t = t_; } while (0)
+#else
+#define DBG_STAMP(slot) do {} while (0)
+#endif
+template <typename T, bool LSUM, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void attn_pf_kernel(const AttnParams p) {
+    typedef typename VT<T>::v8 v8;
+    typedef typename VT<T>::v4 v4;
+    constexpr int NW = 8, QB = 256, IPW = 2, ST = 3;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + NW * 4096];   // [stage][K | V^T] + per-wave Q tile
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
+    const int u = lane >> 5, l31 = lane & 31;
+    // ABL (anatomy builds, wrong results): 1 no in-loop DMA, 2 no fragment reads, 3 group roles swapped (the older waves 0-3 take group 1's
+    // schedule), 4 static s_setprio 1 for waves 4-7, 5 = 1 + 2
+    const int grp = ABL == 3 ? 1 - (wave >> 2) : wave >> 2;   // waves w and w + 4 share a SIMD
+    const float thr = p.pp_thr;
+    if constexpr (ABL == 4) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+#ifdef ATTN_DBG
+    unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = 0;
+#endif
+
+    int b, h, qb;
+    if (!attn_work(p, blockIdx.x, b, h, qb)) return;     // block-uniform
+    const int q_row = qb * QB + wave * 32 + l31;
+
+    {   // Q tile of this wave: 32 rows x 128 B -> LDS (4 DMA instructions, K's swizzle)
+        const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(p.q, p.qbytes);
+        char* dq = smem + ST * 16384 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            int row = qb * QB + wave * 32 + R;
+            row = row < p.Nq ? row : p.Nq - 1;
+            dma16(rs_q, dq + i * 1024, (uint32_t)((((size_t)b * p.Nq + row) * p.ldq + h * 64 + c * 8) * 2));
+        }
+    }
+    const bool pres0 = p.nseg > 0 && b >= p.seg_b0[0];
+    const bool pres1 = p.nseg > 1 && b >= p.seg_b0[1];
+    const int nt0 = pres0 ? (p.nk[0] + 63) >> 6 : 0;
+    const int nt1 = pres1 ? (p.nk[1] + 63) >> 6 : 0;
+    const int nt = nt0 + nt1;
+
+    // ---- loader (as attn_pp_kernel): waves 0-3 fetch K(s), waves 4-7 V^T(s-1); per-lane constants, branch-free issue ----
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int nk0 = p.nk[0], nk1 = p.nk[1];
+    const bool is_k = wave < 4;
+    const int t_shift = is_k ? 0 : 1;
+    uint32_t rowbase[2][IPW], tstep[2];
+    int lim0 = 0;
+    const int lim_x = is_k ? 8 : 32;
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        const size_t bsg = (size_t)(b - p.seg_b0[sg] > 0 ? b - p.seg_b0[sg] : 0);
+        tstep[sg] = is_k ? (uint32_t)(64 * p.ldk[sg] * 2) : 128u;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int R = ((wave * IPW + i) & 7) * 8 + lrow;
+            const int c = lslot ^ ((R >> 1) & 7);
+            rowbase[sg][i] = is_k ? (uint32_t)(((bsg * p.krows[sg] + R) * p.ldk[sg] + h * 64 + c * 8) * 2)
+                                  : (uint32_t)(((bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + c * 8) * 2);
+            if (i == 0) lim0 = is_k ? R : 16 * (c >> 1) + 4 * (c & 1);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs0 = is_k ? make_rsrc(p.k[0], p.kbytes[0]) : make_rsrc(p.vt[0], p.vtbytes[0]);
+    const __amdgpu_buffer_rsrc_t rs1 = is_k ? make_rsrc(p.k[1], p.kbytes[1]) : make_rsrc(p.vt[1], p.vtbytes[1]);
+    auto issue_stage = [&](int s, int bufi) {
+        char* dst = smem + bufi * 16384 + wave * (IPW * 1024);
+        const int t = s - t_shift;
+        const bool in_range = t >= 0 && t < nt;
+        const bool sg1 = t >= nt0;
+        const int kt = sg1 ? t - nt0 : t;
+        const int room = in_range ? (sg1 ? nk1 : nk0) - kt * 64 : 0;
+        const uint32_t toff = (uint32_t)kt * (sg1 ? tstep[1] : tstep[0]);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const uint32_t off = (sg1 ? rowbase[1][i] : rowbase[0][i]) + toff;
+            const int lim = i == 0 ? lim0 : (lim0 ^ lim_x);
+            if (sg1) dma16(rs1, dst + i * 1024, lim < room ? off : OOB_SENTINEL);
+            else dma16(rs0, dst + i * 1024, lim < room ? off : OOB_SENTINEL);
+        }
+    };
+
+    int f_addr[2], f_swz[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; f_addr[kb] = r * 128; f_swz[kb] = (r >> 1) & 7; }
+
+    f32x16 oacc[2], sacc[2], lacc;
+    v8 pf[4], ones, vf[2][4], kf[2][4];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[db][r] = 0.f; sacc[db][r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[ks][j] = (T)0.f;
+    float m_run = 0.f, l_run = 0.f;
+    float thr_cur = -3.0e38f, floor_cur = -3.0e38f;      // first tile: the max is forced to the tile's own row max (see attn_pp_kernel)
+    {
+        int nz = 0;
+        if (p.nseg > 0 && !pres0) nz += p.nk[0];
+        if (p.nseg > 1 && !pres1) nz += p.nk[1];
+        if (nz > 0) {
+            l_run = u == 0 ? (float)nz : 0.f; thr_cur = thr; floor_cur = 0.f;
+            if constexpr (LSUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lacc[r] = (float)nz;
+            }
+        }
+    }
+
+    // ---- prologue: stages 0..2 in flight, Q and stage 0 landed ----
+    const int npro = nt + 1 < ST ? nt + 1 : ST;          // stages 0..nt exist
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+        if (s < npro) issue_stage(s, s);
+    if (npro == 3) wait_vmcnt<2 * IPW>(); else if (npro == 2) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    const char* const dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
+    v8 qf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *(const v8*)(dq + (((2 * s4 + u) ^ ((l31 >> 1) & 7)) << 4));
+
+    auto read_frags = [&](const char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                vf[x][i] = *(const v8*)(buf + 8192 + f_addr[x] + (((2 * i + u) ^ f_swz[x]) << 4));
+                kf[x][i] = *(const v8*)(buf + f_addr[x] + (((2 * i + u) ^ f_swz[x]) << 4));
+            }
+        }
+    };
+    // MFMA block s: PV(s-1) and QK^T(s) on five (four) independent accumulators; S' = K.Q^T - m_run (sacc was seeded with -m_run)
+    auto mfma_block = [&]() {
+        if constexpr (ABL == 6) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            oacc[0] = VT<T>::mfma(vf[0][i], pf[i], oacc[0]);
+            oacc[1] = VT<T>::mfma(vf[1][i], pf[i], oacc[1]);
+            if constexpr (LSUM) lacc = VT<T>::mfma(ones, pf[i], lacc);
+            sacc[0] = VT<T>::mfma(kf[0][i], qf[i], sacc[0]);
+            sacc[1] = VT<T>::mfma(kf[1][i], qf[i], sacc[1]);
+        }
+    };
+    // VALU block j: online softmax of S'(j) -> P(j) (PV B operand); re-seeds sacc with -m_run for QK^T(j+1)
+    auto valu_block = [&](int j) {
+        const bool sg1 = j >= nt0;
+        const int valid = sg1 ? nk1 - (j - nt0) * 64 : nk0 - j * 64;
+        if (valid < 64) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * u;
+                    if (key >= valid) sacc[kb][r] = NEG_BIG;
+                }
+        }
+        float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+        mx = xhalf_max(mx);
+        if (__any(mx > thr_cur)) {
+            const float delta = fmaxf(mx, floor_cur);
+            const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 0.f));
+            l_run *= alpha;
+            if constexpr (LSUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            m_run += delta;
+            thr_cur = thr; floor_cur = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[0][r] -= delta; sacc[1][r] -= delta; }
+        }
+        DBG_STAMP(4);
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r]);
+                if constexpr (!LSUM) { if (r & 1) ps1 += pv; else ps0 += pv; }
+                pf[kb * 2 + (r >> 3)][r & 7] = (T)pv;
+            }
+        if constexpr (!LSUM) l_run += ps0 + ps1;
+        __builtin_amdgcn_sched_barrier(0);
+        DBG_STAMP(5);
+        const float nm = -m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[0][r] = nm; sacc[1][r] = nm; }
+        __builtin_amdgcn_sched_barrier(0);
+        DBG_STAMP(6);
+    };
+    auto phase_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+    // barrier M_s: own share of stage s+1 landed (stage s+2, if it exists, stays in flight), LDS reads of this phase done
+    auto mid_barrier = [&](int s) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 <= nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+    int b0i = 0, b1i = 1;                                // buffers of stage s and stage s + 1
+    auto rotate = [&]() { b0i = b1i; b1i = b1i + 1 == ST ? 0 : b1i + 1; };
+
+#ifdef ATTN_DBG
+    dbg_t = __builtin_readcyclecounter();
+#endif
+    if (grp == 0) {
+        read_frags(smem);                                // F(0)
+        for (int s = 0; s <= nt; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            DBG_STAMP(2);
+            phase_barrier();                             // A_s
+            DBG_STAMP(3);
+            mfma_block();
+            __builtin_amdgcn_sched_barrier(0);
+            DBG_STAMP(0);
+            mid_barrier(s);                              // B_s
+            DBG_STAMP(1);
+            if ((ABL != 2 && ABL < 5) && s + 1 <= nt) read_frags(smem + b1i * 16384);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((ABL != 1 && ABL < 5) && s + 3 <= nt) issue_stage(s + 3, b0i);
+            if (s < nt) valu_block(s);
+            rotate();
+        }
+    } else {
+        for (int s = 0; s <= nt; ++s) {
+            DBG_STAMP(2);
+            phase_barrier();                             // A_s
+            DBG_STAMP(3);
+            if (ABL != 2 && ABL < 5) read_frags(smem + b0i * 16384);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s >= 1) valu_block(s - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            DBG_STAMP(0);
+            mid_barrier(s);                              // B_s
+            DBG_STAMP(1);
+            mfma_block();
+            __builtin_amdgcn_sched_barrier(0);
+            if ((ABL != 1 && ABL < 5) && s + 3 <= nt) issue_stage(s + 3, b0i);
+            rotate();
+        }
+    }
+#ifdef ATTN_DBG
+    if (lane == 0 && blockIdx.x < 4096) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_attn_dbg[(blockIdx.x * 8 + wave) * 8 + i] = dbg_acc[i];
+    }
+#endif
+
+    const float lt = LSUM ? lacc[0] : xhalf_sum(l_run);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    if (q_row < p.Nq) {
+        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 8 * u;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                v4 o[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[k][j] = (T)(oacc[db][8 * gp + 4 * k + j] * inv);
+                store_cols8(op + db * 32 + 16 * gp, o[0], o[1]);
+            }
+    }
+}
+
 template <typename T, int MODE>
 static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
@@ -663,6 +971,36 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
         CHECK_LAUNCH("attn_fwd");
         return IDMVTON_OK;
     }
+    if (((tune >> 16) & 0xff) == 7 || ((tune >> 16) & 0xff) == 8) {   // attn_pf_kernel: fragments prefetched a phase early (7: row sums on the matrix pipe)
+        if (MODE != IDMVTON_ATTN_SELF || !p.q_prescaled)
+            return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: the prefetch kernel needs SELF mode and a pre-multiplied q");
+        static const float thr_tab[4] = {4.f, 0.f, 8.f, 2.f};
+        p.pp_flags = 0;
+        p.pp_thr = thr_tab[(tune >> 26) & 3];
+        dim3 gridp;
+        attn_grid(p, 256, gridp);
+        if (((tune >> 16) & 0xff) == 7) hipLaunchKernelGGL((attn_pf_kernel<T, true>), gridp, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((attn_pf_kernel<T, false>), gridp, dim3(512), 0, st, p);
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
+#ifdef ATTN_DBG
+    if (((tune >> 16) & 0xff) >= 9 && ((tune >> 16) & 0xff) <= 14) {   // anatomy builds of attn_pf_kernel<LSUM>: ABL = selector - 8
+        p.pp_flags = 0; p.pp_thr = 4.f;
+        dim3 gridp;
+        attn_grid(p, 256, gridp);
+        switch ((tune >> 16) & 0xff) {
+        case 9: hipLaunchKernelGGL((attn_pf_kernel<T, true, 1>), gridp, dim3(512), 0, st, p); break;
+        case 10: hipLaunchKernelGGL((attn_pf_kernel<T, true, 2>), gridp, dim3(512), 0, st, p); break;
+        case 11: hipLaunchKernelGGL((attn_pf_kernel<T, true, 3>), gridp, dim3(512), 0, st, p); break;
+        case 12: hipLaunchKernelGGL((attn_pf_kernel<T, true, 4>), gridp, dim3(512), 0, st, p); break;
+        case 13: hipLaunchKernelGGL((attn_pf_kernel<T, true, 5>), gridp, dim3(512), 0, st, p); break;
+        default: hipLaunchKernelGGL((attn_pf_kernel<T, true, 6>), gridp, dim3(512), 0, st, p); break;
+        }
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
+#endif
     if ((tune >> 16) & 0xff) return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: unknown kernel selector in tune");
     dim3 grid;
     attn_grid(p, 32 * nw, grid);

@@ -9,7 +9,7 @@ int idmvton_set_error(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* idmvton_last_error(void) { return g_err; }
-extern "C" int idmvton_abi_version(void) { return 8; }   // 8: gemm_conv tile_hint variant 6 (8-wave 128x128, 320x256), variant 3 and the LayerNorm-fold fields (rowstats_*, ln_*) removed; 7: IDMVTON_IO_OUT_F8 (gemm_conv writes e4m3 q / k / V^T for idmvton_attn_f8); 6: split-precision VAE path (idmvton_split, GN / softmax / layout flags, IDMVTON_IO_BIAS_F32), IDMVTON_MAX_SEG 24
+extern "C" int idmvton_abi_version(void) { return 9; }   // 9: idmvton_prefetch removed (both prefetch forms measured <= 0 in round 5 and have no caller); 8: gemm_conv tile_hint variant 6 (8-wave 128x128, 320x256), variant 3 and the LayerNorm-fold fields (rowstats_*, ln_*) removed; 7: IDMVTON_IO_OUT_F8 (gemm_conv writes e4m3 q / k / V^T for idmvton_attn_f8); 6: split-precision VAE path (idmvton_split, GN / softmax / layout flags, IDMVTON_IO_BIAS_F32), IDMVTON_MAX_SEG 24
 
 // ---- TryonNet input: cat([latents]*2 | mask | masked | pose) -> NHWC[cpad] (tryon_pipeline.py:1769,1777) ----
 template <typename T>
@@ -204,39 +204,6 @@ extern "C" int idmvton_vae_sample(const idmvton_vae_sample_args* a, void* stream
     if (a->dtype == IDMVTON_BF16) hipLaunchKernelGGL((vae_sample_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((vae_sample_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, *a);
     CHECK_LAUNCH("vae_sample");
-    return IDMVTON_OK;
-}
-
-// ---- weight prefetch: pull a byte range towards the chip (the XCD L2 of the touching block and the Infinity Cache) ----
-// One dword per 128-byte line; nothing is computed.  The loads of a thread are issued back to back and consumed by one empty asm
-// statement at the end, so each wave keeps `PF_UNROLL` lines in flight.  Meant to run on a side stream beside the kernels that
-// precede the consumer of the range (the denoising loop streams ~11 GB of weights per step from HBM, every GEMM's first touch
-// of its weight tile is a cold miss; measured: the same GEMM runs 10-40 % faster when its operands are cache resident).
-#define PF_UNROLL 8
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint32_t* base, uint64_t lines) {
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    while (i < lines) {
-        uint32_t v[PF_UNROLL];
-#pragma unroll
-        for (int j = 0; j < PF_UNROLL; ++j) {
-            const uint64_t k = i + j * stride;
-            v[j] = k < lines ? base[k * 32] : 0u;    // default cache policy: the line stays in L2 / Infinity Cache
-        }
-#pragma unroll
-        for (int j = 0; j < PF_UNROLL; ++j) asm volatile("" :: "v"(v[j]));
-        i += PF_UNROLL * stride;
-    }
-}
-extern "C" int idmvton_prefetch(const void* ptr, uint64_t bytes, int blocks, void* stream) {
-    CHECK_ARG(ptr != nullptr && ((uintptr_t)ptr & 3) == 0, IDMVTON_E_ARG, "prefetch: pointer");
-    if (bytes < 128) return IDMVTON_OK;
-    const uint64_t lines = bytes / 128;
-    if (blocks <= 0) blocks = 64;
-    const uint64_t need = (lines + 256 * PF_UNROLL - 1) / (256 * PF_UNROLL);
-    if ((uint64_t)blocks > need) blocks = (int)need;
-    hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)ptr, lines);
-    CHECK_LAUNCH("prefetch");
     return IDMVTON_OK;
 }
 

@@ -17,7 +17,7 @@ GN_X_F32, GN_Y_SPLIT, GN_AFFINE_F32 = 1, 2, 4
 LAYOUT_SPLIT, LAYOUT_NHWC_F32 = 1, 2
 SPLIT_ACT, SPLIT_W3, SPLIT_W3T = 0, 1, 2
 MAX_SEG = 24
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 i32, u32, f32, vp = C.c_int32, C.c_uint32, C.c_float, C.c_void_p
 
@@ -110,7 +110,7 @@ STRUCTS = {"idmvton_seg": Seg, "idmvton_gemm_conv_args": GemmConvArgs, "idmvton_
 SYMBOLS = ["idmvton_last_error", "idmvton_abi_version", "idmvton_sizeof", "idmvton_gemm_conv", "idmvton_attn_fwd",
            "idmvton_layernorm", "idmvton_groupnorm", "idmvton_pack_input", "idmvton_cfg_step", "idmvton_layout",
            "idmvton_vae_sample", "idmvton_softmax_rows", "idmvton_probe_mfma", "idmvton_groupnorm_stats_doubles",
-           "idmvton_prefetch", "idmvton_attn_small", "idmvton_rccl_unique_id", "idmvton_rccl_comm_init", "idmvton_rccl_bcast_arena",
+           "idmvton_attn_small", "idmvton_rccl_unique_id", "idmvton_rccl_comm_init", "idmvton_rccl_bcast_arena",
            "idmvton_rccl_comm_destroy", "idmvton_attn_f8", "idmvton_quant_f8", "idmvton_split"]
 
 _lib = None
@@ -151,8 +151,6 @@ def lib():
     L.idmvton_probe_mfma.argtypes = [C.c_int, vp, vp, vp, vp]
     L.idmvton_groupnorm_stats_doubles.argtypes = [C.c_int] * 4
     L.idmvton_groupnorm_stats_doubles.restype = C.c_int
-    L.idmvton_prefetch.argtypes = [vp, C.c_uint64, C.c_int, vp]
-    L.idmvton_prefetch.restype = C.c_int
     L.idmvton_rccl_unique_id.argtypes = [vp]
     L.idmvton_rccl_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.idmvton_rccl_bcast_arena.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, vp]

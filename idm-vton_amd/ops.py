@@ -428,14 +428,6 @@ def split(x, dtype, mode=ffi.SPLIT_ACT):
     return out
 
 
-def prefetch(t, blocks=0, stream=None):
-    """Touch every 128-byte line of tensor `t` (contiguous storage) on `stream` (default: the current stream)."""
-    st = _stream() if stream is None else stream.cuda_stream
-    rc = ffi.lib().idmvton_prefetch(C.c_void_p(_dev(t).data_ptr()), C.c_uint64(t.numel() * t.element_size()), blocks, C.c_void_p(st))
-    if rc != 0:
-        raise RuntimeError(ffi.lib().idmvton_last_error().decode())
-
-
 def probe_mfma(which, a, b):
     c = torch.empty((64, 16), dtype=torch.float32, device=a.device)
     rc = ffi.lib().idmvton_probe_mfma(which, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),

@@ -194,7 +194,10 @@ class TryonEngine:
     def _noise(self, st, i):
         return st["steps_noise"][i] if st["steps_noise"] is not None else None
 
-    def _denoise_serial_eager(self, st, trace=None):
+    def _denoise_serial_eager(self, st, trace=None, on_step=None):
+        """on_step(i, t, latents) runs after step i on the live latents (it may rewrite them in place); a true return value ends the loop
+        (the reference's per-step callbacks and `interrupt`, tryon_pipeline.py:1766-1767,1840-1863: host code between two steps, which
+        only this un-captured form can run)."""
         fset = None
         for bi, (s0, c) in enumerate(st["blocks"]):
             if fset is None:
@@ -205,6 +208,8 @@ class TryonEngine:
                 self._tryon_main(st, st["temb_t"][i], st["coef"][i], self._noise(st, i), fset["step"][j])
                 if trace is not None:
                     trace.setdefault("step_latents", []).append(st["latents"].clone())
+                if on_step is not None and on_step(i, int(st["timesteps"][i]), st["latents"]):
+                    return st["latents"]
         return st["latents"]
 
     def _denoise_overlap_eager(self, st, trace=None):
@@ -339,8 +344,11 @@ class TryonEngine:
         return sst["latents"]
 
     @torch.no_grad()
-    def denoise(self, st, use_graph=False, trace=None, overlap=False):
-        """The loop.  Four execution forms with bit-identical results: {serial, two-stream overlap} x {eager, hipGraph replay}."""
+    def denoise(self, st, use_graph=False, trace=None, overlap=False, on_step=None):
+        """The loop.  Four execution forms with bit-identical results: {serial, two-stream overlap} x {eager, hipGraph replay}; a per-step
+        host hook (`on_step`) selects the serial eager form."""
+        if on_step is not None:
+            return self._denoise_serial_eager(st, trace, on_step)
         if use_graph:
             return self._denoise_graph(st, overlap, trace)
         return self._denoise_overlap_eager(st, trace) if overlap else self._denoise_serial_eager(st, trace)
@@ -351,7 +359,7 @@ class TryonEngine:
         return (img / 2 + 0.5).clamp(0, 1)                                                 # postprocess
 
     @torch.no_grad()
-    def __call__(self, *, return_latents=False, use_graph=False, overlap=False, timing=None, **kw):
+    def __call__(self, *, return_latents=False, use_graph=False, overlap=False, timing=None, on_step=None, **kw):
         """timing: a list that receives one (start, prepared, denoised, decoded) tuple of HIP events recorded on the current stream
         (bench.py: the loop's share of a timed call without a second, instrumented run)."""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timing is not None else None
@@ -360,7 +368,7 @@ class TryonEngine:
         st = self.prepare(**kw)
         if ev:
             ev[1].record()
-        lat = self.denoise(st, use_graph=use_graph, overlap=overlap)
+        lat = self.denoise(st, use_graph=use_graph, overlap=overlap, on_step=on_step)
         if ev:
             ev[2].record()
         out = lat if return_latents else self.decode(lat)

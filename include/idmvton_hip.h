@@ -326,11 +326,6 @@ typedef struct {
 } idmvton_split_args;
 int idmvton_split(const idmvton_split_args* a, void* stream);
 
-/* Weight prefetch: touches one dword per 128-byte line of [ptr, ptr+bytes) from `blocks` workgroups (0 = 64) so the range is
- * resident in the Infinity Cache / L2 when its consumer starts.  No result; run it on a side stream ahead of the consumer.
- * (No reference counterpart: the reference streams its weights through cuBLAS/cuDNN kernels with no explicit residency.) */
-int idmvton_prefetch(const void* ptr, uint64_t bytes, int blocks, void* stream);
-
 /* ---------------------------------------------------------------------------------------------------------------
  * The path's one collective: start-up broadcast of a packed weight arena from `root` to every rank over RCCL / xGMI.
  * No reference counterpart: every process of the reference loads every checkpoint itself (inference.py:232-274) and there are no

@@ -317,7 +317,7 @@ def stage_vae(Wd, H, W, B=1):
     torch.cuda.synchronize()
 
 
-def run_all(Wd, out_path=None, stages=("anchor", "cfg2_unets", "cfg2_b2_2steps", "cfg2_30steps", "vae", "cfg4_unets", "cfg4_1step")):
+def run_all(Wd, out_path=None, stages=("anchor", "cfg2_unets", "cfg2_b2_2steps", "cfg2_30steps", "cfg2_b2_ddpm30", "vae", "cfg4_unets", "cfg4_1step")):
     def guard(name, fn, *a, **k):
         if name not in stages:
             return
@@ -336,6 +336,9 @@ def run_all(Wd, out_path=None, stages=("anchor", "cfg2_unets", "cfg2_b2_2steps",
     guard("cfg2_unets", stage_unets, Wd, "cfg2", 128, 96, H2, W2)
     guard("cfg2_b2_2steps", stage_loop, Wd, "cfg2_b2_ddpm2", H2, W2, 2, 2, "ddpm", record=(0, 1))
     guard("cfg2_30steps", stage_loop, Wd, "cfg2_b1_ddim30", H2, W2, 1, 30, "ddim", record=(0, 9, 19, 29))
+    # the operating point of the script the boundary drops into: /root/reference/inference.py:232 builds DDPMScheduler and :397-414 runs 30
+    # ancestral steps at batch 2 (CFG batch 4) -- injected per-step noise, latents against the oracle at steps 1, 10, 20, 30
+    guard("cfg2_b2_ddpm30", stage_loop, Wd, "cfg2_b2_ddpm30", H2, W2, 2, 30, "ddpm", record=(0, 9, 19, 29))
     guard("vae", stage_vae, Wd, H2, W2)
     guard("cfg4_unets", stage_unets, Wd, "cfg4", 192, 128, H4, W4)
     guard("cfg4_1step", stage_loop, Wd, "cfg4_b1_ddpm1", H4, W4, 1, 1, "ddpm", record=(0,))

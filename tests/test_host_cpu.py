@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(ffi.SYMBOLS), declared ^ set(ffi.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.idmvton_abi_version() == ffi.ABI_VERSION == 8
+    assert L.idmvton_abi_version() == ffi.ABI_VERSION == 9
 
 
 def test_arg_validation_without_gpu():
