@@ -174,17 +174,35 @@ class _UNetBase(nn.Module):
         self._hip_key = None
 
     def set_default_attn_processor(self):
-        """Reference :854-867: drop custom processors.  The stock processor of this boundary is AttnProcessor2_0 (TryonNet's attn2 layers then
-        lose their IP-Adapter branch, exactly as the reference's would)."""
+        """Reference :854-867: only when every processor is a stock cross-attention processor; anything else -- TryonNet's IPAttnProcessor2_0
+        layers, which are in neither of diffusers' processor sets -- raises ValueError there, and here (silently replacing them would drop
+        the to_k_ip / to_v_ip parameters from the state dict and leave a model whose forward cannot run)."""
+        procs = self.attn_processors
+        if not all(type(p) is AttnProcessor2_0 for p in procs.values()):
+            raise ValueError(f"Cannot call `set_default_attn_processor` when attention processors are of type {next(iter(procs.values()))}")
         self.set_attn_processor(AttnProcessor2_0(), _remove_lora=True)
 
     def set_attention_slice(self, slice_size):
         """Reference :869-932 (sliced attention to save memory).  No-op by construction: the HIP attention kernel is blockwise (online softmax
         over 64-key tiles, csrc/attention.hip) and never materialises a [queries x keys] score matrix, so there is nothing to slice; the
-        argument is validated like the reference's and recorded."""
-        if not (slice_size in ("auto", "max") or isinstance(slice_size, int) or
-                (isinstance(slice_size, (list, tuple)) and all(isinstance(v, int) for v in slice_size))):
+        argument is validated like the reference's (one entry per sliceable layer, none larger than the layer's head count) and recorded."""
+        dims = [m.heads for _, m in self.named_modules() if isinstance(m, Attention)]            # sliceable_head_dim of every attention layer
+        if slice_size == "auto":
+            sizes = [d // 2 for d in dims]
+        elif slice_size == "max":
+            sizes = len(dims) * [1]
+        elif isinstance(slice_size, (list, tuple)):
+            sizes = list(slice_size)
+        elif isinstance(slice_size, int) or slice_size is None:
+            sizes = len(dims) * [slice_size]
+        else:
             raise ValueError(f"slice_size {slice_size!r} must be 'auto', 'max', an int or a list of ints")
+        if len(sizes) != len(dims):
+            raise ValueError(f"You have provided {len(sizes)}, but {self.config} has {len(dims)} different"
+                             f" attention layers. Make sure to match `len(slice_size)` to be {len(dims)}.")
+        for size, dim in zip(sizes, dims):
+            if size is not None and size > dim:
+                raise ValueError(f"size {size} has to be smaller or equal to {dim}.")
         self.attention_slice = slice_size
 
     def fuse_qkv_projections(self):

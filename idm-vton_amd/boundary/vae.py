@@ -47,6 +47,7 @@ class AutoencoderKL(nn.Module):
                                       scaling_factor=cfg.scaling_factor, force_upcast=cfg.force_upcast)
         build_param_tree(self, vae_param_shapes(cfg), torch_dtype, device)
         self._hip, self._hip_key = None, None
+        self.use_slicing = self.use_tiling = False          # diffusers AutoencoderKL.__init__ defaults
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, torch_dtype=torch.float32, **kw):

@@ -61,6 +61,57 @@ static void attn_grid(AttnParams& p, int qrows, dim3& grid) {
     grid = dim3(8 * ((units + 7) / 8) * p.chunk);
 }
 
+// Work order of attn_sp_kernel.  Two cost classes: LONG (b >= lb0: every segment present) and SHORT (b < lb0: the second segment is absent, half
+// the tiles).  The q-blocks of one (batch, head) group walk the same K/V; a group is cut into `parts` runs of `chunk` consecutive q-blocks (a unit:
+// its workgroups go to ONE XCD and share K/V through that L2; parts = 8 / gcd(groups, 8), so that every XCD gets the same number of units of a
+// class), unit U of its class goes to XCD U % 8 (block id i runs on XCD i % 8), and inside every XCD's id sequence long and short workgroups
+// ALTERNATE -- kind(j) = (j ^ (j >> 5)) & 1 for the j-th workgroup of the XCD, so neighbours in dispatch order (j, j + 1) and workgroups one
+// CU-round apart (j, j + 32) differ -- because with two workgroups resident per CU the hardware pairs ids by a rule HIP does not promise;
+// alternating makes every pairing long + short, i.e. every CU carries the same work (the longest-first order of attn_work gave CUs two long or
+// two short walks: no gain over one workgroup per CU).  When one class runs out on an XCD the other continues alone.  Ids beyond an XCD's count
+// (and q-blocks beyond the last) are padding and exit.
+__device__ __forceinline__ bool sp_work(const AttnParams& p, int bid, int& b, int& h, int& qb) {
+    const int x = bid & 7, j = bid >> 3;
+    const int nqb = p.nqb, lb0 = p.chunk;               // (chunk carries lb0, parts the two classes' part counts for this kernel)
+    const int pl = p.parts & 0xffff, psh = p.parts >> 16;
+    const int chl = (nqb + pl - 1) / pl, chs = (nqb + psh - 1) / psh;
+    const int ngl = (p.B - lb0) * p.heads, ngs = lb0 * p.heads;
+    const int cl = ((ngl * pl - x + 7) >> 3) * chl, cs = ((ngs * psh - x + 7) >> 3) * chs;     // this XCD's long / short workgroups
+    const int m = cl < cs ? cl : cs;
+    // ids with kind 0 take long, kind 1 short, while both classes last (2m ids; every aligned pair holds one of each kind, so id j < 2m is the
+    // (j >> 1)-th of its kind)
+    int t; bool lng;
+    if (!(p.pp_flags & 1)) { lng = j < cl; t = lng ? j : j - cl; }      // more workgroups than the chip holds at once: longest first
+    else if (j < 2 * m) { lng = (((j ^ (j >> 5)) & 1) == 0); t = j >> 1; }
+    else { lng = cl > cs; t = j - m; }
+    if (t >= (lng ? cl : cs)) return false;
+    const int ch = lng ? chl : chs, pa = lng ? pl : psh;
+    const int U = (t / ch) * 8 + x, g = U / pa;
+    qb = (U - g * pa) * ch + (t - (t / ch) * ch);
+    b = (lng ? lb0 : 0) + g / p.heads;
+    h = g % p.heads;
+    return qb < nqb;
+}
+static void sp_grid(AttnParams& p, int qrows, dim3& grid) {   // (also sets pp_flags bit 0: see sp_work)
+    p.nqb = (p.Nq + qrows - 1) / qrows;
+    int lb0 = p.nseg > 1 ? p.seg_b0[1] : 0;             // batches below it skip the second segment
+    if (p.nseg > 0 && p.seg_b0[0] > lb0) lb0 = p.seg_b0[0];
+    if (lb0 > p.B) lb0 = p.B;
+    auto parts_of = [&](int ng) {
+        if (ng <= 0) return 1;
+        int g8 = 8;
+        while (ng % g8) g8 >>= 1;                        // gcd(ng, 8)
+        int pa = 8 / g8;
+        return pa < p.nqb ? pa : p.nqb;
+    };
+    const int ngl = (p.B - lb0) * p.heads, ngs = lb0 * p.heads;
+    const int pl = parts_of(ngl), psh = parts_of(ngs);
+    p.chunk = lb0; p.parts = pl | (psh << 16);
+    const int chl = (p.nqb + pl - 1) / pl, chs = (p.nqb + psh - 1) / psh;
+    grid = dim3(8 * (((ngl * pl + 7) / 8) * chl + ((ngs * psh + 7) / 8) * chs));
+    p.pp_flags = (qrows == 128 && grid.x <= 512) ? 1 : 0;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int MODE, int NWAVES, int ST>
@@ -927,12 +978,318 @@ __global__ __launch_bounds__(512, 2) void attn_pf_kernel(const AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_sp_kernel: SELF mode, 8 waves x 32 query rows, every wave SOFTWARE-PIPELINED over three tiles.
+//
+// What bounds head_dim-64 attention on this chip is the SIMD's shared VALU issue port, not the matrix pipe
+// (profiles/r06_probe_mfma_valu_overlap.txt: beside MFMAs a plain VALU instruction costs ~4 cycles of the port, a v_exp_f32 ~8 -- the
+// transcendentals of the two waves of a SIMD do not overlap each other or plain VALU work -- and an MFMA issue ~10; a 64-key tile of one wave
+// needs 32 v_exp).  The ping-pong kernels above (attn_pp / attn_pf) put the softmax of a wave into a phase of its own (a ~650-cycle dependent
+// chain: serial row max -> any() branch -> 32 exponentials -> converts -> accumulator seed) and pay two such phases per tile
+// (profiles/r06_attention_anatomy.txt).  Here no wave waits for its partner and the instruction count per tile is cut to what the port must carry:
+//   * in iteration i a wave issues, as ONE basic block,
+//         matrix pipe :  O^T += V^T(i-2) . P^T(i-2)      and      S'^T(i) = K(i) . Q^T - m          (16 MFMAs)
+//         VALU        :  P^T(i-1) = exp2(S'^T(i-1)), row sum                                         (independent of both products)
+//     so its own softmax runs in the gaps of its own MFMAs and the two waves of a SIMD simply share the port;
+//   * the exponentials are SPECULATIVE: S' already carries -m (accumulator seed), P is exponentiated against the old max before anything about
+//     the tile is known;
+//   * there is NO row-max pass: the per-lane row sum of the tile (needed for l anyway) bounds every P of the lane, so "sum <= LIMIT" proves
+//     that no P exceeded LIMIT (and none overflowed: inf fails the test).  Only when a lane's sum exceeds it (wave-uniform branch AFTER the
+//     block; always on the first tile, practically never later) is the true row max taken, O and l rescaled, P(i-1) re-exponentiated from the
+//     intact S'(i-1) and the in-flight S'(i) shifted -- PV(i-2) is complete at that point, P(i-1) and S'(i) are the only values at the old scale
+//     (the order rule of the deferred rescale).
+// LDS ring of 3 stages, stage i = { K(i) | V^T(i-2) }, one workgroup barrier per tile (counted vmcnt across it); the loader walks the two key
+// segments with running scalar state (one v_add per DMA instruction on full tiles).  Needs q pre-multiplied by softmax_scale * log2(e).
+// ABL (dbg builds, timing only): bit0 no exponentials, bit1 no MFMA, bit2 no LDS fragment reads, bit3 no in-loop DMA, bit4 no barrier.
+template <typename T, int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(const AttnParams p) {
+    typedef typename VT<T>::v8 v8;
+    typedef typename VT<T>::v4 v4;
+    constexpr int QB = 32 * NW, IPW = 16 / NW, ST = 3;    // NW = 8: one workgroup per CU; NW = 4: two (independent) workgroups per CU
+    __shared__ __attribute__((aligned(1024))) char smem[ST * 16384 + NW * 4096];   // [stage][K | V^T] + per-wave Q tile
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform(threadIdx.x >> 6);
+    const int u = lane >> 5, l31 = lane & 31;
+    const float limit = p.pp_thr;                         // row-sum bound that keeps the old max (32 keys per lane at P <= 1 give <= 32)
+
+    int b, h, qb;
+    if (!sp_work(p, blockIdx.x, b, h, qb)) return;       // block-uniform
+    const int q_row = qb * QB + wave * 32 + l31;
+
+    {   // Q tile of this wave: 32 rows x 128 B -> LDS (4 DMA instructions, K's swizzle)
+        const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(p.q, p.qbytes);
+        char* dq = smem + ST * 16384 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            int row = qb * QB + wave * 32 + R;
+            row = row < p.Nq ? row : p.Nq - 1;
+            dma16(rs_q, dq + i * 1024, (uint32_t)((((size_t)b * p.Nq + row) * p.ldq + h * 64 + c * 8) * 2));
+        }
+    }
+    const bool pres0 = p.nseg > 0 && b >= p.seg_b0[0];
+    const bool pres1 = p.nseg > 1 && b >= p.seg_b0[1];
+    const int nt0 = pres0 ? (p.nk[0] + 63) >> 6 : 0;
+    const int nt1 = pres1 ? (p.nk[1] + 63) >> 6 : 0;
+    const int nt = nt0 + nt1;
+    const int nk0 = p.nk[0], nk1 = p.nk[1];
+
+    // ---- loader: waves 0-3 fetch K(i), waves 4-7 V^T(i-2).  The stages are issued strictly in order, so the segment walk is running scalar
+    // state: ld_t = tile of the next stage for this wave (negative: V^T's two-stage lag; >= nt: past the end -> zero fill), ld_off = byte
+    // offset of that tile inside its segment, ld_room = keys of the segment from that tile on, ld_seg = segment. ----
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const bool is_k = wave < NW / 2;
+    // per-lane byte offsets of this wave's IPW DMA rows inside segment sg (tile 0).  Only the CURRENT segment's set lives in registers; it is
+    // recomputed at the segment switch.  lane_lim(i): the smallest key index piece i fetches (only a segment's partial last tile needs it).
+    uint32_t rb[IPW];
+    auto seg_base = [&](int sg) {
+        const size_t bsg = (size_t)(b - p.seg_b0[sg] > 0 ? b - p.seg_b0[sg] : 0);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int R = ((wave * IPW + i) & 7) * 8 + lrow;
+            const int c = lslot ^ ((R >> 1) & 7);
+            rb[i] = is_k ? (uint32_t)(((bsg * p.krows[sg] + R) * p.ldk[sg] + h * 64 + c * 8) * 2)
+                         : (uint32_t)(((bsg * p.heads * 64 + h * 64 + R) * p.ldvt[sg] + c * 8) * 2);
+        }
+    };
+    auto lane_lim = [&](int i) {
+        const int R = ((wave * IPW + i) & 7) * 8 + lrow;
+        const int c = lslot ^ ((R >> 1) & 7);
+        return is_k ? R : 16 * (c >> 1) + 4 * (c & 1);
+    };
+    const uint32_t tstep0 = is_k ? (uint32_t)(64 * p.ldk[0] * 2) : 128u, tstep1 = is_k ? (uint32_t)(64 * p.ldk[1] * 2) : 128u;
+    const __amdgpu_buffer_rsrc_t rs0 = is_k ? make_rsrc(p.k[0], p.kbytes[0]) : make_rsrc(p.vt[0], p.vtbytes[0]);
+    const __amdgpu_buffer_rsrc_t rs1 = is_k ? make_rsrc(p.k[1], p.kbytes[1]) : make_rsrc(p.vt[1], p.vtbytes[1]);
+    int ld_t = is_k ? 0 : -2, ld_room = nt0 > 0 ? nk0 : nk1;
+    bool ld_seg1 = nt0 == 0;
+    uint32_t ld_off = 0;
+    seg_base(ld_seg1 ? 1 : 0);
+    auto issue_next = [&](int bufi) {
+        char* dst = smem + bufi * 16384 + wave * (IPW * 1024);
+        if (ld_t < 0 || ld_t >= nt) {                    // outside the walk: zero fill (all lanes out of range)
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) dma16(rs0, dst + i * 1024, OOB_SENTINEL);
+        } else {
+            if (!ld_seg1 && ld_t == nt0) { ld_seg1 = true; ld_off = 0; ld_room = nk1; seg_base(1); }
+            if (ld_room >= 64) {                          // full tile: no per-lane masking
+#pragma unroll
+                for (int i = 0; i < IPW; ++i) { if (ld_seg1) dma16(rs1, dst + i * 1024, rb[i] + ld_off); else dma16(rs0, dst + i * 1024, rb[i] + ld_off); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < IPW; ++i) {
+                    const uint32_t off = lane_lim(i) < ld_room ? rb[i] + ld_off : OOB_SENTINEL;
+                    if (ld_seg1) dma16(rs1, dst + i * 1024, off); else dma16(rs0, dst + i * 1024, off);
+                }
+            }
+            ld_off += ld_seg1 ? tstep1 : tstep0;
+            ld_room -= 64;
+        }
+        ++ld_t;
+    };
+
+    int f_addr[2], f_swz[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int r = kb * 32 + l31; f_addr[kb] = r * 128; f_swz[kb] = (r >> 1) & 7; }
+
+    f32x16 oacc[2], sA[2], sB[2];
+    v8 P[4];                                              // P^T of ONE tile: PV(i-2) reads it early in a block, the converts of tile i-1 rewrite it late
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[db][r] = 0.f; sA[db][r] = 0.f; sB[db][r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P[ks][j] = (T)0.f;
+    // m_run starts at 0 (S' = S).  Without a closed-form segment the first tile FORCES the max to its own row max (whatever its sign: lim_cur < 0
+    // sends it through the rescale branch); with one (nk keys of logit 0, value 0: m = 0, l = nk) the ordinary rule applies from the first tile on.
+    float m_run = 0.f, l_run = 0.f;
+    float lim_cur = -1.f, floor_cur = -3.0e38f;
+    {
+        int nz = 0;
+        if (p.nseg > 0 && !pres0) nz += nk0;
+        if (p.nseg > 1 && !pres1) nz += nk1;
+        if (nz > 0) { l_run = u == 0 ? (float)nz : 0.f; lim_cur = limit; floor_cur = 0.f; }
+    }
+
+    // ---- prologue: stages 0, 1 in flight; Q and stage 0 landed ----
+    const int last = nt + 1;                              // stages 0 .. nt + 1 exist
+    issue_next(0);
+    issue_next(1);
+    wait_vmcnt<IPW>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    const char* const dq = smem + ST * 16384 + wave * 4096 + l31 * 128;
+    v8 qf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *(const v8*)(dq + (((2 * s4 + u) ^ ((l31 >> 1) & 7)) << 4));
+
+    auto k_frag = [&](const char* buf, int kb, int s4) { return *(const v8*)(buf + f_addr[kb] + (((2 * s4 + u) ^ f_swz[kb]) << 4)); };
+    auto v_frag = [&](const char* buf, int db, int ks) { return *(const v8*)(buf + 8192 + f_addr[db] + (((2 * ks + u) ^ f_swz[db]) << 4)); };
+
+    // top of iteration i: stage i landed for every wave, every wave done with stage i-1's buffer -> refill it with stage i+2
+    int cbuf = 0, ibuf = 2;
+    auto sync_stage = [&](int i) -> const char* {
+        if (i + 1 <= last) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
+        if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (!(ABL & 8) && i + 2 <= last) issue_next(ibuf);
+        const char* buf = smem + cbuf * 16384;
+        cbuf = cbuf + 1 == ST ? 0 : cbuf + 1;
+        ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
+        return buf;
+    };
+
+    // One iteration = block(i) + tail(i).  block: exp(i-1) [Scur -> Pcur, speculative], PV(i-2) [Pprev], QK^T(i) [-> Snext, seeded with -m], one
+    // basic block; tail: the row-sum test, the rare fixup, l, and the seed of Scur (the next iteration's Snext).  jvalid = keys of tile i-1.
+    auto block = [&](int jvalid, const char* buf, f32x16 (&Scur)[2], f32x16 (&Snext)[2], float (&ps)[4]) {
+        if (jvalid < 64) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * u;
+                    if (key >= jvalid) Scur[kb][r] = NEG_BIG;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- one basic block: 16 MFMAs, 16 LDS reads, 32 exponentials + converts + the row sum ----
+        v8 vf[2][4], kf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (ABL & 4) { vf[0][ks] = qf[ks]; vf[1][ks] = qf[ks]; kf[0][ks] = qf[ks]; kf[1][ks] = qf[ks]; }
+            else { vf[0][ks] = v_frag(buf, 0, ks); vf[1][ks] = v_frag(buf, 1, ks); kf[0][ks] = k_frag(buf, 0, ks); kf[1][ks] = k_frag(buf, 1, ks); }
+        }
+        if constexpr (!(ABL & 2)) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                oacc[0] = VT<T>::mfma(vf[0][ks], P[ks], oacc[0]);
+                oacc[1] = VT<T>::mfma(vf[1][ks], P[ks], oacc[1]);
+                Snext[0] = VT<T>::mfma(kf[0][ks], qf[ks], Snext[0]);
+                Snext[1] = VT<T>::mfma(kf[1][ks], qf[ks], Snext[1]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(vf[0][ks]), "v"(vf[1][ks]), "v"(kf[0][ks]), "v"(kf[1][ks]), "v"(P[ks]));
+        }
+        ps[0] = ps[1] = ps[2] = ps[3] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = (ABL & 1) ? Scur[kb][r] : __builtin_amdgcn_exp2f(Scur[kb][r]);
+                ps[r & 3] += pv;
+                P[kb * 2 + (r >> 3)][r & 7] = (T)pv;     // (after the PV MFMA that read the old P[kb * 2 + (r >> 3)]: same registers)
+            }
+        // the speculative P must exist at the end of this block (hipcc otherwise sinks the exponentials behind the branch of the tail, into both arms)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(P[ks]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tail = [&](f32x16 (&Scur)[2], f32x16 (&Snext)[2], float (&ps)[4]) {
+        float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);   // this lane's 32 keys; every P of the lane is <= psum
+        if (__any(!(psum <= lim_cur))) {                 // rare (always on the first tile): some P may be large -- take the true row max
+            float mx = fmaxf(Scur[0][0], Scur[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, Scur[0][r]), Scur[1][r]);
+            mx = xhalf_max(mx);
+            const float delta = fmaxf(mx, floor_cur);    // later tiles: the max never moves down
+            const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 0.f));   // (first tile: O = l = 0, keep alpha finite)
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            m_run += delta;
+            lim_cur = limit; floor_cur = 0.f;
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(Scur[kb][r] - delta);
+                    if (r & 1) q1 += pv; else q0 += pv;
+                    P[kb * 2 + (r >> 3)][r & 7] = (T)pv;
+                    Snext[kb][r] -= delta;
+                }
+            psum = q0 + q1;
+        }
+        l_run += psum;
+        const float nm = -m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Scur[0][r] = nm; Scur[1][r] = nm; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- iteration 0: QK^T(0) only ----
+    {
+        const char* buf = sync_stage(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sA[0] = VT<T>::mfma(k_frag(buf, 0, ks), qf[ks], sA[0]);
+            sA[1] = VT<T>::mfma(k_frag(buf, 1, ks), qf[ks], sA[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- iterations 1 .. nt, two per trip (the S register sets trade places); jv = keys of tile i-1 that exist (running scalar).
+    // (Measured and dropped: rotating the schedule of waves 4-7 by the tail -- block(i) sync(i+1) tail(i) -- so that one wave's barrier / test /
+    // seed section lies beside its SIMD partner's MFMA block: +5 % time, profiles/r06_attention_sp_ablation.txt.)
+    float ps[4];
+    int i = 1, jv = nt0 > 0 ? nk0 : nk1;
+    auto next_valid = [&](int ii) { jv -= 64; if (ii == nt0 && nt1 > 0) jv = nk1; };   // called after iteration ii: tile ii's count
+    for (; i + 1 <= nt; i += 2) {
+        const char* buf = sync_stage(i);
+        block(jv, buf, sA, sB, ps);
+        tail(sA, sB, ps);
+        next_valid(i);
+        buf = sync_stage(i + 1);
+        block(jv, buf, sB, sA, ps);
+        tail(sB, sA, ps);
+        next_valid(i + 1);
+    }
+    if (i <= nt) {                                        // one iteration left
+        const char* buf = sync_stage(i);
+        block(jv, buf, sA, sB, ps);
+        tail(sA, sB, ps);
+    }
+    // ---- iteration nt + 1: PV(nt-1) only, then normalise and store (lane holds O[q][h*64 + db*32 + 8g + 4u + j]) ----
+    if (nt > 0) {
+        const char* buf = sync_stage(nt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            oacc[0] = VT<T>::mfma(v_frag(buf, 0, ks), P[ks], oacc[0]);
+            oacc[1] = VT<T>::mfma(v_frag(buf, 1, ks), P[ks], oacc[1]);
+        }
+    }
+    const float lt = xhalf_sum(l_run);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    if (q_row < p.Nq) {
+        T* op = (T*)p.out + ((size_t)b * p.Nq + q_row) * p.ldo + h * 64 + 8 * u;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                v4 o[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[k][j] = (T)(oacc[db][8 * gp + 4 * k + j] * inv);
+                store_cols8(op + db * 32 + 16 * gp, o[0], o[1]);
+            }
+    }
+}
+
 template <typename T, int MODE>
 static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     // 32 query rows per wave.  Pick waves/block so the grid has >= ~2 workgroups per CU when the problem allows it.
     // tune = (flags << 24) | (kernel << 16) | (ST << 8) | waves overrides (tuning table / tests); ST: 2 = two-buffer loop, 3/4 = LDS ring;
     // kernel = 2 | 3: attn_pp_kernel (3: one workgroup per CU, deep fragment prefetch); flags: bit0 pair adjacent waves, bit1 no
-    // setprio, bits 2-3 rescale-threshold selector.
+    // setprio, bits 2-3 rescale-threshold selector.  kernel = 7 | 8: attn_pf_kernel (row sums on the matrix pipe | on the VALU).  kernel = 16:
+    // attn_sp_kernel, waves 8 | 4 (256 | 128 query rows per workgroup), flags bits 2-3 = row-sum limit selector.
     // No tune: 8 waves (256 query rows per workgroup: fewest K/V re-reads) while that still gives most CUs a workgroup,
     // else 4 waves with the 3-stage ring, 2 waves only for tiny problems (measured rule, profiles/r01_tune_report_*.json).
     const long bh = (long)p.B * p.heads;
@@ -940,7 +1297,12 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
     if (bh * ((p.Nq + 255) / 256) >= 200) { nw = 8; stg = 2; }
     else if (bh * ((p.Nq + 127) / 128) < 64 && p.Nq <= 64) { nw = 2; stg = 2; }
     if (tune) { nw = tune & 0xff; stg = (tune >> 8) & 0xff; }
-    else if (MODE == IDMVTON_ATTN_SELF && bh * ((p.Nq + 255) / 256) >= 200 && p.Nq >= 1024) {
+    else if (MODE == IDMVTON_ATTN_SELF && p.q_prescaled && p.Nq >= 128) {
+        // measured (profiles/r06_attention_sp_tuner_lines.txt, r06_attention_variants.txt): the software-pipelined kernel, 256 query rows per
+        // workgroup when that still gives every CU several of them, else 128 (two workgroups per CU, long + short walks paired)
+        nw = (bh * ((p.Nq + 255) / 256) >= 400 && p.Nq >= 2048) ? 8 : 4; stg = 3;
+        tune = (16 << 16) | (3 << 8) | nw;
+    } else if (MODE == IDMVTON_ATTN_SELF && bh * ((p.Nq + 255) / 256) >= 200 && p.Nq >= 1024) {
         tune = (2 << 16) | (2 << 8) | 8; nw = 8; stg = 2;   // measured (profiles/r02_probe_attn_*): the ping-pong kernel wins on the long walks
     }
     if (((tune >> 16) & 0xff) == 2 || ((tune >> 16) & 0xff) == 3) {   // ping-pong kernel (3: one workgroup per CU, deep fragment prefetch)
@@ -984,7 +1346,36 @@ static int launch_attn(AttnParams& p, int tune, hipStream_t st) {
         CHECK_LAUNCH("attn_fwd");
         return IDMVTON_OK;
     }
+    if (((tune >> 16) & 0xff) == 16) {   // attn_sp_kernel (software-pipelined, speculative exponentials, row-sum overflow test)
+        if (MODE != IDMVTON_ATTN_SELF || !p.q_prescaled)
+            return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: the software-pipelined kernel needs SELF mode and a pre-multiplied q");
+        static const float lim_tab[4] = {512.f, 32.f, 8192.f, 128.f};   // row-sum limits (tune bits 26-27): P <= limit while the max is kept
+        p.pp_thr = lim_tab[(tune >> 26) & 3];
+        dim3 gridp;
+        if (nw == 4) {                                   // 128 query rows per workgroup, two workgroups per CU: finer units for short / uneven walks
+            sp_grid(p, 128, gridp);
+            hipLaunchKernelGGL((attn_sp_kernel<T, 4>), gridp, dim3(256), 0, st, p);
+        } else {
+            sp_grid(p, 256, gridp);
+            hipLaunchKernelGGL((attn_sp_kernel<T, 8>), gridp, dim3(512), 0, st, p);
+        }
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
 #ifdef ATTN_DBG
+    if (((tune >> 16) & 0xff) >= 32 && ((tune >> 16) & 0xff) < 160) {   // ablation builds of attn_sp_kernel<row sums on the VALU> (timing only): selector - 32 = mask
+        p.pp_flags = 0; p.pp_thr = 512.f;                               // 1 no exponentials, 2 no MFMA, 4 no LDS reads, 8 no in-loop DMA, 16 no barrier
+        dim3 gridp;
+        sp_grid(p, 256, gridp);
+        switch (((tune >> 16) & 0xff) - 32) {                            // + 32 / + 64: every wave on group 0's / group 1's schedule (no rotation)
+#define SPA(m) case m: hipLaunchKernelGGL((attn_sp_kernel<T, 8, m>), gridp, dim3(512), 0, st, p); break;
+        SPA(0) SPA(1) SPA(2) SPA(3) SPA(4) SPA(8) SPA(12) SPA(15) SPA(16) SPA(31) SPA(29)
+#undef SPA
+        default: return idmvton_set_error(IDMVTON_E_ARG, "attn_fwd: ablation mask not built");
+        }
+        CHECK_LAUNCH("attn_fwd");
+        return IDMVTON_OK;
+    }
     if (((tune >> 16) & 0xff) >= 9 && ((tune >> 16) & 0xff) <= 14) {   // anatomy builds of attn_pf_kernel<LSUM>: ABL = selector - 8
         p.pp_flags = 0; p.pp_thr = 4.f;
         dim3 gridp;

@@ -71,6 +71,15 @@ def c_abi_comm():
     return comm
 
 
+def observed_world():
+    """World size as the communicator reports it (not the WORLD_SIZE variable); 1 when no process group exists."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else "none (single process)"
+
+
 def broadcast_arena(flat, src=0, chunk_elems=1 << 28, via=None):
     """Broadcast a flat weight arena from `src` in <= 512 MiB (bf16) pieces.  No-op for world size 1.
     via = "torch" (default; torch.distributed.broadcast: backend "nccl" IS RCCL on ROCm, gloo on CPU) or "c_abi" (the C ABI's

@@ -41,9 +41,12 @@ def _call(fn_name, args, flops=0.0, bytes_=0.0):
     PROFILE.append((fn_name, e0, e1, flops, bytes_))
 
 
-# Per-shape kernel configuration table measured on an MI355X by tools/gpu_tune.py (every entry was checked there against the
-# default configuration's output on the real operands before it was admitted).  Missing file / missing key => the
-# library's built-in heuristic (tile_hint / tune = 0).
+# Per-shape kernel configuration table measured on an MI355X by tools/gpu_tune.py.  The tuner runs the bf16 engine and checks every entry
+# against the default configuration's output on the real bf16 operands before admitting it; the fp16 keys are MIRRORS of those entries
+# (load_tune below) and launches with IDMVTON_IO_OUT_F8 share the key of the plain launch, so for fp16 and e4m3 output the guarantee is not
+# the tuner's but the suite's: tests/kernel_checks.py runs every (variant, BN, BM) of the table in both storage dtypes (RING_TILES) and with
+# e4m3 output (gemm_f8_out_*), and tests/test_host_cpu.py checks that list against the table.  Missing file / missing key => the library's
+# built-in heuristic (tile_hint / tune = 0).
 # IDMVTON_TUNE_TABLE=<file>: another tuning table than the committed one (A/B of two tables on one box; measurement only)
 TUNE_PATH = os.environ.get("IDMVTON_TUNE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_gfx950.json")
 _TUNE = {"gemm": {}, "attn": {}}

@@ -81,9 +81,15 @@ class _PConv:
 
 
 class HipVAE:
+    @property
+    def precise_decode(self):
+        """Read-only after __init__ (the 16-bit decoder's weights are not built for precise_decode=True and vice versa): construct another
+        HipVAE for an A/B."""
+        return self._precise_decode
+
     def __init__(self, cfg: VAEConfig, state_dict, dtype=torch.bfloat16, device="cuda", precise_decode=True):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
-        self.precise_decode = bool(precise_decode)
+        self._precise_decode = bool(precise_decode)         # fixed at construction: only the chosen decoder's weights are prepared
         if self.precise_decode:
             self._prep_precise({k: v.to(device=self.device, dtype=torch.float32) for k, v in state_dict.items()
                                 if k.startswith(("decoder.", "post_quant_conv."))})

@@ -166,7 +166,13 @@ typedef struct {
                                     tile, stages 2 (two-buffer) | 3 | 4 (LDS ring), waves 2|4|8 (any mode).  kernel 2|3: the ping-pong kernel
                                     (SELF mode, 8 waves, stages 2|3; 2 = two workgroups per CU, 3 = one per CU with every fragment of a block
                                     prefetched); flags bit0 = pair waves (w, w^1) instead of (w, w+4), bit1 = no s_setprio, bits 2..3 =
-                                    deferred-rescale threshold selector {0: 4, 1: 0 (exact skip only), 2: 8, 3: 2} in log2 units */
+                                    deferred-rescale threshold selector {0: 4, 1: 0 (exact skip only), 2: 8, 3: 2} in log2 units.
+                                    kernel 7|8: the ping-pong kernel with each MFMA block's fragments read from LDS one phase early (3 stages;
+                                    7 = row sums on the matrix pipe); needs q_prescaled.  kernel 16: the software-pipelined kernel (every wave
+                                    overlaps the exponentials of tile i-1 with the MFMAs of PV(i-2) and QK^T(i); exponentials are speculative
+                                    and a row-sum bound replaces the row max), waves 8 | 4 = 256 | 128 query rows per workgroup, flags bits
+                                    2..3 = row-sum limit selector {0: 512, 1: 32, 2: 8192, 3: 128}; SELF mode, needs q_prescaled.  auto picks
+                                    kernel 16 for SELF launches with a pre-multiplied q and >= 128 query rows */
     int32_t q_prescaled;         /* 1: q is already multiplied by softmax_scale * log2(e) = 0.125 * 1.4426950408889634 (gemm_conv's colscale
                                     applies it in fp32 in the projection epilogue, same single rounding as an unscaled q) */
 } idmvton_attn_args;

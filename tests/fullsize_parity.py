@@ -123,8 +123,9 @@ class World:
 
     def dump(self, path):
         os.makedirs(os.path.dirname(path), exist_ok=True)
+        import bench
         with open(path, "w") as f:
-            json.dump(dict(results=self.results, seconds=self.timing,
+            json.dump(dict(results=self.results, seconds=self.timing, source_hash=bench.kernel_source_hash(),
                            metric="rel = max|x-ref|/max|ref|, rms = ||x-ref||/||ref||; ref = fp32 oracle, same weights / inputs / noise"), f, indent=1)
 
 

@@ -771,6 +771,17 @@ RING_TILES = ((_hint(5, 256, 256), "h5f0"), (_hint(5, 256, 257), "h5f1"),
               (_hint(1, 64, 64), "r64x64"))
 
 
+# tile families run with IDMVTON_IO_OUT_F8 (gemm_f8_out_* below)
+F8_OUT_TILES = (("auto", 0), ("r128x128", _hint(1, 128, 128)), ("r128x256", _hint(1, 128, 256)), ("r256x256", _hint(1, 256, 256)),
+               ("p64x64", _hint(2, 64, 64)), ("w8_128x128", _hint(6, 128, 128)), ("v0_128x128", _hint(0, 128, 128)), ("h256", _hint(5, 256, 256)), ("h256f1", _hint(5, 256, 257)),
+               ("h192", _hint(5, 256, 192)),
+               # ... and every other (variant, BN, BM) of idm-vton_amd/tune_gfx950.json: ops.load_tune mirrors the bf16-measured entries onto the
+               # fp16 keys and gemm_key has no io_flags, so IDMVTON_IO_OUT_F8 launches of the fp16+fp8 engine select these tiles too
+               ("w8p_128x128", _hint(6, 128, 129)), ("w12_256x192", _hint(6, 256, 192)), ("w12_320x192", _hint(6, 320, 192)),
+               ("w16_256x256", _hint(6, 256, 256)), ("w16_128x256", _hint(6, 128, 256)), ("p128x256", _hint(2, 128, 256)),
+               ("v0_64x64", _hint(0, 64, 64)), ("r64x64", _hint(1, 64, 64)))
+
+
 def all_checks(dev="cuda"):
     """(name, thunk, tolerance) for every kernel-level check; sizes are the reference's real shapes where cheap."""
     out = []
@@ -867,6 +878,25 @@ def all_checks(dev="cuda"):
                         add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn, prescaled=True))
                         add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn, prescaled=True))
                         add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn, prescaled=True))
+        # round 6: attn_pf_kernel (fragments read a phase early: kernel 7 row sums on the matrix pipe, 8 on the VALU) and attn_sp_kernel (software-
+        # pipelined, speculative exponentials, row-sum overflow test instead of a row max: kernel 16 with 8 waves = 256 query rows per workgroup or
+        # 4 waves = 128; tune bits 26-27 select the row-sum limit {512, 32, 8192, 128}) -- every edge case of the ping-pong list, incl. the inputs that
+        # FORCE the rescale branch late in the key walk (spike: logits tower over a row's earlier keys; with limit 32 ordinary tiles take it too)
+        for kern, nw, tag0 in ((7, 8, "pf_lsum"), (8, 8, "pf_vsum"), (16, 8, "sp8"), (16, 4, "sp4")):
+            for sel in (0, 1, 2, 3) if kern == 16 else (0, 2):
+                tn, tag = (sel << 26) | (kern << 16) | (3 << 8) | nw, f"{tag0}_sel{sel}"
+                add(f"attn_self_2seg_cfg_N768_{tag}", lambda dt=dt, tn=tn: check_attn_self(4, 4, 768, dt, dev, n_garm=768, b0=2, tune=tn, prescaled=True))
+                add(f"attn_self_ragged_N200_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 200, dt, dev, n_garm=200, b0=1, tune=tn, prescaled=True))
+                add(f"attn_self_odd_tiles_N320_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 320, dt, dev, n_garm=192, b0=1, tune=tn, prescaled=True))
+                add(f"attn_self_big_logits_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 2, 256, dt, dev, n_garm=256, b0=1, scale=4.0, tune=tn, prescaled=True))
+                add(f"attn_self_N16_{tag}", lambda dt=dt, tn=tn: check_attn_self(2, 1, 16, dt, dev, n_garm=16, b0=1, tune=tn, prescaled=True))
+                add(f"attn_self_one_tile_N64_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 1, 64, dt, dev, tune=tn, prescaled=True))
+                add(f"attn_self_two_tiles_N128_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 2, 128, dt, dev, tune=tn, prescaled=True))
+                add(f"attn_self_1seg_N1000_{tag}", lambda dt=dt, tn=tn: check_attn_self(1, 3, 1000, dt, dev, tune=tn, prescaled=True))
+                add(f"attn_self_b0_3_of_5_h3_{tag}", lambda dt=dt, tn=tn: check_attn_self(5, 3, 300, dt, dev, n_garm=130, b0=3, tune=tn, prescaled=True))
+                add(f"attn_self_spike_{tag}", lambda dt=dt, tn=tn: check_attn_spike(dt, dev, tune=tn, prescaled=True))
+                add(f"attn_self_neg_logits_{tag}", lambda dt=dt, tn=tn: check_attn_neg(dt, dev, tune=tn, prescaled=True))
+            add(f"attn_self_N3072_h10_{tag0}", lambda dt=dt, kern=kern, nw=nw: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=(kern << 16) | (3 << 8) | nw, prescaled=True))
         add("attn_self_N3072_h10_pp_s3d1", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=pp_tune(3, 1)))
         add("attn_self_N3072_h10_pp_s2d0", lambda dt=dt: check_attn_self(4, 10, 3072, dt, dev, n_garm=3072, b0=2, tune=pp_tune(2, 0)))
         add("attn_self_spike", lambda dt=dt: check_attn_spike(dt, dev))
@@ -885,9 +915,7 @@ def all_checks(dev="cuda"):
             add(f"attn_f8_kernel_only_{nm}", lambda dt=dt, a=args: check_attn_f8(a[0], a[1], a[2], dt, dev, n_garm=a[3], b0=a[4])[1], 3e-2)
         add("quant_f8", lambda dt=dt: check_quant_f8(dt, dev), 0.0)
         # the projections of the fp8 path writing e4m3 themselves (IDMVTON_IO_OUT_F8), on every tile family the tuned table may select
-        for hn, hv in (("auto", 0), ("r128x128", _hint(1, 128, 128)), ("r128x256", _hint(1, 128, 256)), ("r256x256", _hint(1, 256, 256)),
-                       ("p64x64", _hint(2, 64, 64)), ("w8_128x128", _hint(6, 128, 128)), ("v0_128x128", _hint(0, 128, 128)), ("h256", _hint(5, 256, 256)), ("h256f1", _hint(5, 256, 257)),
-                       ("h192", _hint(5, 256, 192))):
+        for hn, hv in F8_OUT_TILES:
             add(f"gemm_f8_out_{hn}", lambda dt=dt, hv=hv: check_gemm_f8_out(dt, dev, B=2, N=192, C=256, K=320, hint=hv), 0.0)
         add("gemm_f8_out_N768_C640", lambda dt=dt: check_gemm_f8_out(dt, dev, B=4, N=768, C=640, K=640), 0.0)
         add("gemm_f8_out_bias_free_kv_only", lambda dt=dt: check_gemm_f8_kv(dt, dev), 0.0)

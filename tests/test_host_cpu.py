@@ -275,9 +275,11 @@ def test_tuning_table_entries_decode_to_supported_kernel_configurations():
     for key, v in t["attn"].items():
         assert len(key.split(",")) == 9
         flags, kernel, st, nw = (v >> 24) & 0xf, (v >> 16) & 0xff, (v >> 8) & 0xff, v & 0xff
-        assert kernel in (0, 2, 3), (key, v)                                      # attn_kernel | ping-pong | ping-pong, one workgroup per CU
+        assert kernel in (0, 2, 3, 7, 8, 16), (key, v)     # attn_kernel | ping-pong | ping-pong, one workgroup per CU | prefetch (2) | software-pipelined
         if kernel == 0:
             assert nw in (2, 4, 8) and st in (2, 3, 4) and flags == 0, (key, v)
+        elif kernel == 16:
+            assert nw in (4, 8) and int(key.split(",")[1]) == 0, (key, v)          # 128 / 256 query rows per workgroup; SELF mode only
         else:
             assert nw == 8 and st in (2, 3) and int(key.split(",")[1]) == 0, (key, v)   # SELF mode only
 
@@ -427,3 +429,19 @@ def test_gemm_conv_f8_refuses_what_the_c_contract_refuses():
         ops.gemm_conv([ops.SegSpec(x, 0, 64)], w, 64, out=out, res=x, f8=(1.0, 1.0))
     with pytest.raises(ValueError, match="multiple of 64"):
         ops.gemm_conv([ops.SegSpec(x, 0, 64)], w, 64, out=out[:, :0], vt=torch.zeros(2, 64, 32, dtype=torch.uint8), vt_n0=0, vt_tokens=32, f8=(1.0, 1.0))
+
+
+def test_every_tuned_tile_is_checked_in_both_dtypes_and_with_e4m3_output():
+    """ops.load_tune mirrors the bf16-measured table onto the fp16 keys and IDMVTON_IO_OUT_F8 launches share the key of the plain launch
+    (ADVICE r5): the guarantee for those is the kernel suite's, so every (variant, BN, BM) the table holds must be in the lists
+    tests/kernel_checks.py runs per storage dtype (RING_TILES, plus the variant-0 hints of all_checks) and with e4m3 output (F8_OUT_TILES)."""
+    import json
+    import os
+    from tests import kernel_checks as kc
+    table = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "idm-vton_amd", "tune_gfx950.json")))
+    tiles = {(v >> 28, (v >> 16) & 0xfff, v & 0xffff) for v in table["gemm"].values() if v}
+    dec = lambda h: (h >> 28, (h >> 16) & 0xfff, h & 0x3fff)           # bit 14 of BM = the persistent-walk form of the same tile
+    ring = {dec(h) for h, _ in kc.RING_TILES} | {(0, 128, 128), (0, 128, 64), (0, 64, 64)}
+    f8 = {dec(h) for _, h in kc.F8_OUT_TILES}
+    assert tiles <= ring, sorted(tiles - ring)
+    assert tiles <= f8, sorted(tiles - f8)

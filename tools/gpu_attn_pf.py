@@ -10,14 +10,16 @@ from tests import kernel_checks as kc
 
 dev = torch.device("cuda")
 pf = lambda k, thr=0: (thr << 26) | (k << 16) | (3 << 8) | 8
-VARIANTS = [("pp_s2d0", kc.pp_tune(2, 0)), ("pp_s2d1", kc.pp_tune(2, 1)), ("pp_s3d1", kc.pp_tune(3, 1)), ("pf_lsum", pf(7)), ("pf_vsum", pf(8))]
+VARIANTS = [("pp_s2d0", kc.pp_tune(2, 0)), ("pp_s2d1", kc.pp_tune(2, 1)), ("pf_vsum", pf(8)), ("sp8", pf(16)), ("sp4", (16 << 16) | (3 << 8) | 4)]
+TIMING_ONLY = []
+CHECK = os.environ.get("CHECK", "sp")
 if len(sys.argv) > 1:
     VARIANTS += [(f"k{k}", pf(int(k))) for k in sys.argv[1].split(",")]
 
 bad = 0
 for dt in (torch.bfloat16, torch.float16):
     for name, tn in VARIANTS:
-        if not name.startswith(("pf", "k")):
+        if not name.startswith((CHECK, "k")):
             continue
         for thr in (0, 1, 2):
             t = tn | (thr << 26)
@@ -57,21 +59,21 @@ def timed(fn, n=60):
     return e0.elapsed_time(e1) * 1e3 / n
 
 for dt in (torch.bfloat16, torch.float16):
-    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev, dt)
-    for (B, heads, N, b0) in ((4, 10, 3072, 2), (4, 20, 768, 2), (2, 10, 3072, 2), (2, 20, 768, 2), (2, 10, 6144, 1), (2, 20, 1536, 1)):
+    r = lambda *s, sc=float(os.environ.get('SC', '0.35')): (torch.randn(*s, generator=g) * sc).to(dev, dt)
+    for (B, heads, N, b0) in ((4, 10, 3072, 2), (4, 20, 768, 2), (12, 10, 3072, 12), (12, 20, 768, 12), (2, 10, 6144, 1), (2, 20, 1536, 1)):
         C = heads * 64
         qk = r(B * N, 2 * C)
-        vt = r(B, C, N)
+        vt = r(B, C, N, sc=1.0)
         segs = [dict(k=qk[:, C:], vt=vt, nk=N, ldk=2 * C, ldvt=N)]
         if b0 < B:
             Bg = B - b0
-            segs.append(dict(k=r(Bg * N, C), vt=r(Bg, C, N), nk=N, ldk=C, ldvt=N, b0=b0))
+            segs.append(dict(k=r(Bg * N, C), vt=r(Bg, C, N, sc=1.0), nk=N, ldk=C, ldvt=N, b0=b0))
         out = torch.empty(B * N, C, dtype=dt, device=dev)
         keys = sum(N * (B - s.get("b0", 0)) for s in segs)
         fl = 4.0 * N * 64 * heads * keys
         line = []
         for rep in range(2):
-            for name, tn in VARIANTS:
+            for name, tn in VARIANTS + TIMING_ONLY:
                 t = timed(lambda: ops.attention(qk, out, segs, heads, B=B, Nq=N, ldq=2 * C, ldo=C, q_prescaled=True, tune=tn))
                 if rep == 1:
                     line.append(f"{name}={t:.1f}us/{fl / t / 1e6:.0f}TF")

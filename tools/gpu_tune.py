@@ -35,7 +35,9 @@ def pp_tune(stages, deep, pair=0, noprio=0, thr=0):
 
 
 ATTN_CANDS = [(f"w{nw}s{st}", (st << 8) | nw) for nw in (2, 4, 8) for st in (2, 3, 4)] + \
-             [(f"pp_s{st}d{dp}", pp_tune(st, dp)) for st in (2, 3) for dp in (0, 1)]
+             [(f"pp_s{st}d{dp}", pp_tune(st, dp)) for st in (2, 3) for dp in (0, 1)] + \
+             [("pf", (8 << 16) | (3 << 8) | 8),                                        # round 6: fragments prefetched a phase early
+              ("sp8", (16 << 16) | (3 << 8) | 8), ("sp4", (16 << 16) | (3 << 8) | 4)]   # software-pipelined, 256 / 128 query rows per workgroup
 
 
 def main():
@@ -46,6 +48,7 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--skip-ring", action="store_true", help="do not consider the LDS-ring GEMM variants")
     ap.add_argument("--skip-attn-variants", action="store_true", help="do not consider non-default attention variants")
+    ap.add_argument("--only-attn", action="store_true", help="tune the attention launches only; the GEMM half of the written table is the committed one")
     ap.add_argument("--warm-weights", action="store_true", help="touch the weights back into the cache before every timed launch (the pre-round-4 regime)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tune_gfx950.json"))
     args = ap.parse_args()
@@ -86,11 +89,14 @@ def main():
         ffi.call(fn, a, stream)
 
     import ctypes as C
-    L = ffi.lib()
+    hip = C.CDLL("libamdhip64.so")
+    scratch = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 
     def touch(ptr, nbytes):
+        """Read [ptr, ptr + nbytes) back towards the chip (device-to-device copy into a scratch buffer on the launch stream): the state an
+        activation is in when its consumer starts right behind its producer.  (Until round 5 this was the C ABI's idmvton_prefetch, removed in v9.)"""
         if ptr and nbytes >= 128:
-            L.idmvton_prefetch(C.c_void_p(ptr), C.c_uint64(nbytes), 0, C.c_void_p(stream))
+            hip.hipMemcpyAsync(C.c_void_p(scratch.data_ptr()), C.c_void_p(ptr), C.c_size_t(min(nbytes, scratch.numel())), 3, C.c_void_p(stream))
 
     def timed(fn, a):
         for _ in range(2):
@@ -119,7 +125,11 @@ def main():
     table = {"gemm": {}, "attn": {}}
     report = []
     tot_def = tot_best = 0.0
+    if args.only_attn:
+        table["gemm"] = dict(json.load(open(ops.TUNE_PATH)).get("gemm", {}))
     for (kind, key), u in sorted(uniq.items(), key=lambda kv: -kv[1]["weight"]):
+        if args.only_attn and kind != "attn":
+            continue
         a, keep = u["a"], u["keep"]
         if kind == "gemm":
             fn, cands, field = "idmvton_gemm_conv", gemm_cands, "tile_hint"
