@@ -235,7 +235,12 @@ def attention(q, out, segs, heads, *, mode=ffi.ATTN_SELF, ip_scale=1.0, B=None, 
         a.nk[i], a.k_rows[i], a.seg_b0[i] = s["nk"], s.get("k_rows", 0), s.get("b0", 0)
     a.ip_scale = ip_scale
     a.q_prescaled = int(bool(q_prescaled))
-    a.tune = tune if tune else _TUNE["attn"].get(attn_key(a), 0)
+    a.tune = tune
+    if not tune:
+        t = _TUNE["attn"].get(attn_key(a), 0)
+        # the table is measured on the engine's launches, which pre-multiply q; kernels that REQUIRE that (7 / 8: attn_pf, 16: attn_sp) are not
+        # applied to a launch with a raw q (the key does not carry the flag): the library's own rule picks a kernel for it
+        a.tune = t if (q_prescaled or ((t >> 16) & 0xff) not in (7, 8, 16)) else 0
     if RECORD is not None:
         RECORD.append(("attn", attn_key(a), type(a).from_buffer_copy(a), (q, out, segs)))
     fl = 0.0

@@ -37,8 +37,11 @@ class _PConv:
     unless every w_lo is zero -- [N][taps * Cin] of w_lo (against hi again); a fused 1x1 shortcut the same way on its own input pair.
     `segs(x_pair, k, pad)` builds the matching K-segments.  bias fp32."""
 
-    def __init__(self, w32, b32, cin_pad=None, shortcut=None, pad_out_to=None):
+    def __init__(self, w32, b32, cin_pad=None, shortcut=None, pad_out_to=None, hi_only=False):
+        """hi_only: the one-term product hi . w_hi (the activation's bf16 rounding only: 1x the MFMA work) -- for the layers where the decode
+        bar does not need the low halves (HipVAE.HI_ONLY)."""
         dev = w32.device
+        self.hi_only = hi_only
         if w32.dim() == 2:
             w32 = w32[:, :, None, None]
         co, ci, kh, kw = w32.shape
@@ -46,7 +49,11 @@ class _PConv:
         wk = torch.zeros(co, kh * kw, self.cin, dtype=torch.float32, device=dev)
         wk[..., :ci] = w32.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
         hi, lo, self.three = _hi_lo(wk)
-        parts = [torch.cat([hi, hi], dim=2).reshape(co, -1)]
+        if hi_only:
+            self.three = False
+            parts = [hi.reshape(co, -1)]
+        else:
+            parts = [torch.cat([hi, hi], dim=2).reshape(co, -1)]
         if self.three:
             parts.append(lo.reshape(co, -1))
         b = b32.float().clone() if b32 is not None else torch.zeros(co, dtype=torch.float32, device=dev)
@@ -56,7 +63,11 @@ class _PConv:
             ws32 = ws32.reshape(ws32.shape[0], ws32.shape[1]).float()
             shi, slo, self.sc_three = _hi_lo(ws32)
             self.sc_cin = ws32.shape[1]
-            parts.append(torch.cat([shi, shi], dim=1))
+            if hi_only:
+                self.sc_three = False
+                parts.append(shi)
+            else:
+                parts.append(torch.cat([shi, shi], dim=1))
             if self.sc_three:
                 parts.append(slo)
             b = b + bs32.float()
@@ -70,6 +81,11 @@ class _PConv:
         """xp: activation pair [..., 2*cin]; extra: the shortcut's input pair [..., 2*sc_cin]."""
         k, c = self.k, self.cin
         taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)] if k > 1 else [(0, 0)]
+        if self.hi_only:                                     # the hi half of each pair only
+            out = [ops.SegSpec(xp, 0, c, dy, dx) for dy, dx in taps]
+            if self.sc_cin:
+                out.append(ops.SegSpec(extra, 0, self.sc_cin))
+            return out
         out = [ops.SegSpec(xp, 0, 2 * c, dy, dx) for dy, dx in taps]
         if self.three:
             out += [ops.SegSpec(xp, 0, c, dy, dx) for dy, dx in taps]
@@ -257,17 +273,18 @@ class HipVAE:
     # ---- split-precision decode (module docstring) ----
     PDT = torch.bfloat16                                     # operand pairs are bf16 whatever the engine's storage type: fp32's exponent range
 
-    def _prep_precise(self, sd32):
+    def _prep_precise(self, sd32, hi_only=()):
         cfg = self.cfg
+        self._sd32_dec = sd32 if getattr(self, "_keep_sd32", False) else None
         boc, L = cfg.block_out_channels, cfg.layers_per_block
         self.p32 = {k: v.contiguous() for k, v in sd32.items() if ".norm" in k or ".group_norm" in k or k.endswith("conv_norm_out.weight")
                     or k.endswith("conv_norm_out.bias")}
         pc = self.pconvs = {}
 
         def res(p, cin, cout):
-            pc[p + ".conv1"] = _PConv(sd32[p + ".conv1.weight"], sd32[p + ".conv1.bias"])
+            pc[p + ".conv1"] = _PConv(sd32[p + ".conv1.weight"], sd32[p + ".conv1.bias"], hi_only=(p + ".conv1") in hi_only)
             sc = (sd32[p + ".conv_shortcut.weight"], sd32[p + ".conv_shortcut.bias"]) if cin != cout else None
-            pc[p + ".conv2"] = _PConv(sd32[p + ".conv2.weight"], sd32[p + ".conv2.bias"], shortcut=sc)
+            pc[p + ".conv2"] = _PConv(sd32[p + ".conv2.weight"], sd32[p + ".conv2.bias"], shortcut=sc, hi_only=(p + ".conv2") in hi_only)
 
         lc = cfg.latent_channels
         pq = torch.zeros(64, 64, dtype=torch.float32, device=self.device)
@@ -288,7 +305,7 @@ class HipVAE:
                 res(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else out, out)
             if i != len(boc) - 1:
                 u = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                pc[u] = _PConv(sd32[u + ".weight"], sd32[u + ".bias"])
+                pc[u] = _PConv(sd32[u + ".weight"], sd32[u + ".bias"], hi_only=u in hi_only)
         pc["decoder.conv_out"] = _PConv(sd32["decoder.conv_out.weight"], sd32["decoder.conv_out.bias"], pad_out_to=8)
 
     def _pgn(self, x32, name, silu):
