@@ -17,7 +17,7 @@ def timed(fn, n=60):
         fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-MASKS = [0, 32, 1, 2, 3, 4, 8, 12, 44, 15, 16, 31, 29, 64]
+MASKS = [0, 32, 1, 33, 0, 32]
 names = {1: "softmax", 2: "mfma", 4: "ldsread", 8: "dma", 16: "barrier", 32: "rotation", 64: "(all waves group 0 else 1)"}
 for (B, heads, N, b0) in ((4, 10, 3072, 2), (4, 20, 768, 2)):
     C = heads * 64
