@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_conv_kernel(const Gemm
     else {
         // grouped raster: the ~32-64 tiles an XCD runs concurrently form a ~1024 x 1024 output patch (GM m-tiles tall), so
         // the operand rows they share stay in that XCD's 4 MiB L2 instead of being re-fetched per tile row
-        constexpr int GM = 1024 / BM;
+        const int GM = p.gm > 0 ? p.gm : 1024 / BM;
         const int width = GM * p.tiles_n;
         const int grp = wg / width, rem = wg - grp * width;
         const int first = grp * GM;
@@ -304,7 +304,7 @@ template <typename T, int BN, int BM, int WN, int WM, int ST, int OCC>
 __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_xattn_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[ST * (BN + BM) * 128];
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    constexpr int GM = 1024 / BM;
+    const int GM = p.gm > 0 ? p.gm : 1024 / BM;
     const int width = GM * p.tiles_n;
     const int grp = wg / width, rem = wg - grp * width;
     const int first = grp * GM;
@@ -314,7 +314,9 @@ __global__ __launch_bounds__(WN * WM * 64, OCC) void gemm_xattn_kernel(const Gem
 }
 
 template <typename T, int BN, int BM, int WN, int WM, int ST, bool V1, int OCC, bool PFX = false>
-static void launch_cfg(const GemmParams& p, bool lin, hipStream_t st) {
+static void launch_cfg(const GemmParams& p0, bool lin, hipStream_t st) {
+    GemmParams p = p0;
+    p.gm = V1 ? idmvton_choose_gm(p.tiles_m, p.tiles_n, BM, BN, p.Ktot) : 0;
     const dim3 grid(p.tiles_n * p.tiles_m), block(WN * WM * 64);
     if constexpr (V1) {                                  // the v0 kernels keep the one general loader
         if (lin) { hipLaunchKernelGGL((gemm_conv_kernel<T, BN, BM, WN, WM, ST, true, true, OCC, PFX>), grid, block, 0, st, p); return; }

@@ -15,12 +15,17 @@ struct GemmParams {
     void* vt; int vt_n0; int vt_tokens; int vt_perm;
     int colscale_n; float colscale;
     int tiles_m, tiles_n;
+    int gm;                                              // grouped raster: m-tiles per group (idmvton_choose_gm; 0 = 1024 rows)
     int wide;                                            // every epilogue operand allows 16-byte accesses at multiples of 8 columns
     int res32, out32;                                    // fp32 residual stream (io_flags): res read / out written as fp32 (wide only)
     int bias32;                                          // bias holds fp32 (plain 16-byte epilogue only): the split-precision VAE path
     int out8; float o8_scale, vt8_scale;                 // IDMVTON_IO_OUT_F8: out / vt are e4m3 bytes (plain 16-byte epilogue; vt in attention_f8.hip's slot order)
     XAttnParams xa;                                      // mode IDMVTON_EPI_XATTN: cross-attention applied to the accumulators (xattn.cuh)
 };
+
+// Raster group height for a launch of tiles_m x tiles_n tiles of bm x bn (gemm_conv.hip): the choice that makes the eight XCDs fetch the fewest
+// operand panels, see there.
+int idmvton_choose_gm(int tiles_m, int tiles_n, int bm, int bn, int K);
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

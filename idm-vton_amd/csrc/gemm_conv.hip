@@ -25,10 +25,63 @@
 // gemm_tiles_*.hip (one family per translation unit, so the library builds in parallel).
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "gemm_body.cuh"
 
 // gemm_lin.hip: the hand-scheduled Linear main loop (variant 5: 256x256 as 8 waves x 128x64, 256x192 as 8 waves x 64x96)
 int launch_gemm_lin(const GemmParams& p, bool bf16, int bm, int form, int grid_cap, hipStream_t st);
+
+// ---- raster group height ------------------------------------------------------------------------------------------------------------
+// Workgroup ids are remapped so that XCD x runs the x-th eighth of the tile order (xcd_remap), and the order is a grouped raster: groups of GM
+// m-tiles, inside a group n-tile major.  Each XCD has a private 4 MiB L2, so it fetches (from HBM / the Infinity Cache) every A row-panel
+// (BM x K) and every W row-panel (BN x K) its tiles touch: the launch costs sum_x (|M_x| BM + |N_x| BN) K 2 bytes of operand traffic whatever the
+// algorithmic size is.  The product runs GM = 1024 / BM (return value 0).  Round 6 measured the alternative: walking the
+// order for every GM and taking the one with the smallest sum, subject to a group's A panels fitting a share of the L2 (IDMVTON_GM_MODEL=1,
+// cap IDMVTON_GM_CAP_KB, default 2048).  It does what it says to the counters on the single-round launches (3072 x 1280 x 1280: 46 -> 37 MB,
+// 9216 x 1280 x 1280: 90 -> 74 MB, ff2 171 -> 152 MB; with a 6 MiB cap the many-round launches thrash instead: 9216 x 10240 477 -> 685 MB) and
+// the pipeline gets SLOWER with every cap tried (38.7 -> 39.3 / 39.4 / 39.7 ms per denoising step at 4 / 1 / 2 MiB, same box, interleaved:
+// profiles/r06_gemm_traffic_table.txt): these launches are bound by the per-CU LDS fill path, not by L2 misses, and the tile table was
+// tuned on the 1024-row order.  So the model stays a measurement switch.  IDMVTON_GM=<n> forces a value.
+#include <map>
+#include <mutex>
+#include <tuple>
+int idmvton_choose_gm(int tiles_m, int tiles_n, int bm, int bn, int K) {
+    static const char* env = getenv("IDMVTON_GM");
+    if (env) return atoi(env);
+    static const bool model = getenv("IDMVTON_GM_MODEL") && atoi(getenv("IDMVTON_GM_MODEL")) != 0;
+    if (!model) return 0;
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int>, int> cache;
+    const auto key = std::make_tuple(tiles_m, tiles_n, bm, bn, K);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const int T = tiles_m * tiles_n, q = T / 8, r = T % 8;
+    static const long cap = getenv("IDMVTON_GM_CAP_KB") ? atol(getenv("IDMVTON_GM_CAP_KB")) << 10 : (2l << 20);
+    long best = -1; int best_gm = 0;
+    for (int gm = 1; gm <= tiles_m; ++gm) {
+        if (gm > 1 && (long)gm * bm * K * 2 > cap) break;
+        long cost = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, n = x < r ? q + 1 : q;
+            int m_lo = tiles_m, m_hi = -1;               // an XCD's run is contiguous in the order: its m-tiles and n-tiles are counted exactly
+            std::vector<char> ms(tiles_m, 0), ns(tiles_n, 0);
+            int cm = 0, cn = 0;
+            for (int wg = lo; wg < lo + n; ++wg) {
+                const int width = gm * tiles_n, grp = wg / width, rem = wg - grp * width, first = grp * gm;
+                const int gsz = tiles_m - first < gm ? tiles_m - first : gm;
+                const int tn = rem / gsz, tm = first + (rem - tn * gsz);
+                if (!ms[tm]) { ms[tm] = 1; ++cm; }
+                if (!ns[tn]) { ns[tn] = 1; ++cn; }
+            }
+            (void)m_lo; (void)m_hi;
+            cost += (long)cm * bm + (long)cn * bn;
+        }
+        if (best < 0 || cost < best) { best = cost; best_gm = gm; }
+    }
+    cache[key] = best_gm;
+    return best_gm;
+}
 
 static int launch_gemm(const GemmParams& p0, bool bf16, int variant, int bn, int bm, bool lin, hipStream_t st) {
     GemmParams p = p0;
@@ -148,7 +201,7 @@ extern "C" int idmvton_gemm_conv(const idmvton_gemm_conv_args* a, void* stream) 
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1; p.res = a->res; p.ldr = a->ldr; p.mode = a->mode;
     p.vt = a->vt; p.vt_n0 = a->vt_n0; p.vt_tokens = a->vt_tokens > 0 ? a->vt_tokens : 4; p.vt_perm = a->vt_perm ? 1 : 0;
     p.colscale_n = a->colscale_n; p.colscale = a->colscale;
-    p.tiles_m = p.tiles_n = 0;
+    p.tiles_m = p.tiles_n = 0; p.gm = 0;
     {
         auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
         const int n_out = geglu ? a->N / 2 : a->N;

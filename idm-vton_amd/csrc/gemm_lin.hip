@@ -61,7 +61,7 @@ __device__ __forceinline__ void gemm_lin_persistent(const GemmParams& p, char* s
     const int ntiles = p.tiles_m * p.tiles_n, G = gridDim.x;
     auto coords = [&](int idx, int& m0, int& n0) {
         const int wg = xcd_remap(idx, ntiles);
-        constexpr int GM = 1024 / BM;                    // grouped raster (gemm_conv_kernel): an XCD's concurrent tiles form a ~1024-row output patch
+        const int GM = p.gm > 0 ? p.gm : 1024 / BM;      // grouped raster (gemm_conv_kernel): an XCD's concurrent tiles form a GM-tile-tall output patch
         const int width = GM * p.tiles_n;
         const int grp = wg / width, rem = wg - grp * width;
         const int first = grp * GM;
@@ -269,7 +269,9 @@ static int persistent_grid(int ntiles, int grid_cap) {
     return ntiles < cap ? ntiles : cap;
 }
 template <typename T>
-static int launch_lin(const GemmParams& p, int bm, int form, int grid_cap, hipStream_t st) {
+static int launch_lin(const GemmParams& p0, int bm, int form, int grid_cap, hipStream_t st) {
+    GemmParams p = p0;
+    p.gm = idmvton_choose_gm(p.tiles_m, p.tiles_n, bm, 256, p.Ktot);
     const dim3 grid(persistent_grid(p.tiles_n * p.tiles_m, grid_cap)), block(512);
     if (bm == 192) hipLaunchKernelGGL((gemm_lin_kernel<T, 192, 4, 2, 0, 2>), grid, block, 0, st, p);
     else if (form == 0) hipLaunchKernelGGL((gemm_lin_kernel<T, 256, 2, 4, 0, 2>), grid, block, 0, st, p);

@@ -2,7 +2,9 @@
 #include "gemm_body.cuh"
 
 template <typename T>
-static int run(const GemmParams& p, int bn, int bm, int w8, hipStream_t st) {
+static int run(const GemmParams& p0, int bn, int bm, int w8, hipStream_t st) {
+    GemmParams p = p0;
+    p.gm = idmvton_choose_gm(p.tiles_m, p.tiles_n, bm, bn, p.Ktot);
     const dim3 grid(p.tiles_n * p.tiles_m);
     if (bn == 128 && bm == 128 && w8) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 128, 2, 4, 3, 2>), grid, dim3(512), 0, st, p);   // 64x32 per wave
     else if (bn == 128 && bm == 64) hipLaunchKernelGGL((gemm_xattn_kernel<T, 128, 64, 2, 2, 3, 2>), grid, dim3(256), 0, st, p);
