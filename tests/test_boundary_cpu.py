@@ -144,6 +144,7 @@ def test_memory_toggles_of_the_call_surface_exist_and_keep_the_model_intact(tmp_
     set_default_attn_processor (src/unet_hacked_tryon.py:854-1004): a caller that toggles them must not hit AttributeError; they are
     honest no-ops (already blockwise / already fused) that leave weights and processors usable."""
     pipe = _round_trip(tmp_path)
+    assert pipe.vae.use_slicing is False and pipe.vae.use_tiling is False    # diffusers' defaults, readable before any toggle
     pipe.enable_vae_slicing(); assert pipe.vae.use_slicing is True
     pipe.disable_vae_slicing(); assert pipe.vae.use_slicing is False
     pipe.enable_vae_tiling(); assert pipe.vae.use_tiling is True
@@ -151,10 +152,18 @@ def test_memory_toggles_of_the_call_surface_exist_and_keep_the_model_intact(tmp_
     t = pipe.unet
     before = {k: v.clone() for k, v in t.state_dict().items()}
     procs = dict(t.attn_processors)
-    for s in ("auto", "max", 4, [2, 2]):
+    n_attn = len(procs)
+    for s in ("auto", "max", 1, [1] * n_attn):
         t.set_attention_slice(s)
     with pytest.raises(ValueError, match="slice_size"):
         t.set_attention_slice("half")
+    with pytest.raises(ValueError, match="different attention layers"):      # reference :921-925: one entry per sliceable layer
+        t.set_attention_slice([2, 2])
+    with pytest.raises(ValueError, match="has to be smaller or equal"):      # reference :927-931
+        t.set_attention_slice(10 ** 6)
+    with pytest.raises(ValueError, match="Cannot call `set_default_attn_processor`"):   # reference :854-865: IP processors are in neither set
+        t.set_default_attn_processor()
+    assert all(t.attn_processors[k] is procs[k] for k in procs)
     t.fuse_qkv_projections()
     assert t.original_attn_processors.keys() == procs.keys()
     t.unfuse_qkv_projections()

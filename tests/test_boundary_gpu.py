@@ -162,6 +162,28 @@ def test_pipeline_boundary_end_to_end():
               text_embeds_cloth=inp["text_embeds_cloth"], noise=dict(latents=n_lat, masked=n_masked, pose=n_pose, cloth=n_cloth, steps=n_steps),
               num_inference_steps=steps, guidance_scale=2.0, ip_hidden_states=torch.cat([neg, pos]), scheduler="ddpm")
     assert torch.equal(img_pt, ref)
+    # per-step callbacks and `interrupt` (/root/reference/src/tryon_pipeline.py:1766-1767,1840-1863) run the engine's serial un-captured loop:
+    # same latents as the captured loop, the callback sees every step's latents, a replaced `latents` is used, an interrupt skips the rest
+    seen = []
+
+    def cb(p_, i, t_, kw_):
+        seen.append((i, int(t_), kw_["latents"].clone()))
+        return {}
+    torch.manual_seed(123)
+    lat_plain = pipe(generator=torch.Generator(DEV).manual_seed(7), output_type="latent", **call)[0]
+    torch.manual_seed(123)
+    lat_cb = pipe(generator=torch.Generator(DEV).manual_seed(7), output_type="latent", callback_on_step_end=cb, **call)[0]
+    assert torch.equal(lat_plain, lat_cb) and [i for i, _, _ in seen] == list(range(steps))
+    assert torch.equal(seen[-1][2].float(), lat_cb.to(seen[-1][2].dtype).float())
+
+    def stop_after_first(p_, i, t_, kw_):
+        p_._interrupt = True
+        return {"latents": torch.zeros_like(kw_["latents"])}
+    torch.manual_seed(123)
+    lat_int = pipe(generator=torch.Generator(DEV).manual_seed(7), output_type="latent", callback_on_step_end=stop_after_first, **call)[0]
+    assert float(lat_int.abs().max()) == 0.0                      # step 0's latents replaced by zeros, every later step skipped
+    with pytest.raises(NotImplementedError, match="callback_on_step_end_tensor_inputs"):
+        pipe(output_type="latent", callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["prompt_embeds"], **call)
     # the other two branches of __call__: strength < 1 (draw order: init-image posterior FIRST, then the latent noise; 5 steps * 0.6
     # -> the last 3) and guidance_scale <= 1 (no CFG: negative embeddings unused, conditional IP rows only)
     torch.manual_seed(123)
