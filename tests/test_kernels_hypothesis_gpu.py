@@ -44,6 +44,19 @@ def test_self_attention_any_shape(B, heads, n16, g16, dt, b0f, pre, tune):
 
 
 @CFG
+@given(B=st.integers(1, 5), heads=st.integers(1, 5), n16=st.integers(1, 40), g16=st.integers(0, 40), dt=DT, b0f=st.integers(0, 5),
+       kern=st.sampled_from([(16, 8), (16, 4), (7, 8), (8, 8)]), sel=st.integers(0, 3), scale=st.sampled_from([0.3, 1.0, 3.0]))
+def test_self_attention_round6_kernels_any_shape(B, heads, n16, g16, dt, b0f, kern, sel, scale):
+    """attn_sp_kernel (8 / 4 waves) and attn_pf_kernel on drawn shapes: any multiple of 16 tokens (one tile, odd tile counts, ragged last tiles),
+    garment segment of another length, any split of the batch into unconditional / conditional elements (the work order's two classes, either
+    may be empty), every row-sum limit / rescale threshold, small and large logits."""
+    b0 = min(b0f, B)
+    tune = (sel << 26) | (kern[0] << 16) | (3 << 8) | kern[1]
+    e = kc.check_attn_self(B, heads, 16 * n16, dt, DEV, n_garm=16 * g16 if b0 < B else 0, b0=b0, scale=scale, tune=tune, prescaled=True)
+    assert e <= kc.TOL[dt], (B, heads, 16 * n16, 16 * g16, b0, dt, kern, sel, scale, e)
+
+
+@CFG
 @given(B=st.integers(1, 4), heads=st.integers(1, 5), n16=st.integers(1, 48), dt=DT, scale=st.sampled_from([0.0, 0.5, 1.0, 2.0]))
 def test_cross_attention_any_shape(B, heads, n16, dt, scale):
     e = kc.check_attn_cross(B, heads, 16 * n16, dt, DEV, ip_scale=scale)
