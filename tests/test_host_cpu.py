@@ -386,6 +386,9 @@ def test_bench_rank_logic_at_world_8_under_gloo(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["rccl_ranks"] == 8
+    # the start-up weight broadcast is timed and reported (here: the stand-in's 4 MiB arena over gloo; every rank checked it received rank 0's values)
+    wb = d["weight_broadcast"]
+    assert wb["bcast_bytes"] == 4 << 20 and wb["calls"] == 1 and wb["bcast_s"] > 0 and wb["GB_per_s"] > 0 and wb["backend"] == "gloo"
     # the slowest rank sleeps 30 ms per call: the job's time is the max over ranks, the value counts all 8 ranks' images
     assert 0.03 * 3 * 0.9 <= d["ms_per_step"] * 3 / 1e3 <= 5.0
     assert abs(d["value"] - 8 * 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
