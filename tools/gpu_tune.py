@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--skip-ring", action="store_true", help="do not consider the LDS-ring GEMM variants")
     ap.add_argument("--skip-attn-variants", action="store_true", help="do not consider non-default attention variants")
+    ap.add_argument("--garment-steps", type=int, default=0, help="GarmentNet timesteps per batch (0: the engine's default)")
+    ap.add_argument("--merge", action="store_true", help="start from the committed table: signatures this run does not see keep their entries")
     ap.add_argument("--only-attn", action="store_true", help="tune the attention launches only; the GEMM half of the written table is the committed one")
     ap.add_argument("--warm-weights", action="store_true", help="touch the weights back into the cache before every timed launch (the pre-round-4 regime)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tune_gfx950.json"))
@@ -61,6 +63,9 @@ def main():
     torch.cuda.set_device(0)
     engine, _ = bench.build_engine(dt, dev, 0, 30)
     inp = bench.synth_inputs(args.batch, args.height, args.width, 30, dev, 0)
+    if args.garment_steps:
+        engine.garment_steps = args.garment_steps
+        engine.ramp = False                              # one steady block of the chosen size
 
     ops.RECORD = []
     with torch.no_grad():
@@ -125,6 +130,9 @@ def main():
     table = {"gemm": {}, "attn": {}}
     report = []
     tot_def = tot_best = 0.0
+    if args.merge:
+        old = json.load(open(ops.TUNE_PATH))
+        table = {"gemm": dict(old.get("gemm", {})), "attn": dict(old.get("attn", {}))}
     if args.only_attn:
         table["gemm"] = dict(json.load(open(ops.TUNE_PATH)).get("gemm", {}))
     for (kind, key), u in sorted(uniq.items(), key=lambda kv: -kv[1]["weight"]):
@@ -177,6 +185,8 @@ def main():
         row["best_us"] = round(best_t, 2)
         if best_val:
             table[kind][key] = best_val
+        else:
+            table[kind].pop(key, None)
         tot_def += t_def * u["weight"]
         tot_best += best_t * u["weight"]
         report.append(row)
